@@ -1,0 +1,105 @@
+/*
+ * jpeg_amd.h -- C ABI of libjpeg_amd.so, the MI355X (gfx950) implementation of
+ * the Fulim13/jpeg block-transform hot path.  Plain pointers and sizes only.
+ * Citations name the reference interface each entry point stands in for
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     jpegamd_last_error() then describes the failure (thread-local text).
+ *   - "_dev" entry points take DEVICE pointers, enqueue on `stream`
+ *     (a hipStream_t passed as void*, NULL = the default stream), allocate
+ *     nothing and do not synchronise.  The others take HOST pointers, allocate
+ *     and free device memory per call and return when the result is in place
+ *     (the ownership model of kernel.cu:97-104 / 160-164).
+ *   - quantisation tables are 64 host int32 in natural (row-major) order with
+ *     entries 1..255, as main.cpp:64-80 builds them.
+ *   - images are interleaved 3 x u8 in cv::imread's channel order (B,G,R), with
+ *     `stride` bytes between rows; rows and cols must be multiples of 16
+ *     (encode_decode.cpp:29-37 guarantees it before the path is entered).
+ *   - coefficient planes: one int16 per coefficient, 64 per 8x8 block in the
+ *     reference's zigzag order (encode_decode.cpp:312-348), blocks in raster
+ *     order with ceil(cols/8) blocks per block-row (encode_decode.cpp:233-258).
+ */
+#ifndef JPEG_AMD_H
+#define JPEG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Selects `device` for the calling thread and checks that it is a gfx950.
+ * Fails loudly if there is no usable GPU: there is no CPU fallback. */
+int jpegamd_init(int device);
+const char *jpegamd_last_error(void);
+/* Library/ABI version, bumped when a signature changes. */
+int jpegamd_abi_version(void);
+
+/* ---- legacy block boundary --------------------------------------------- */
+/* kernel.cuh:6-7 / kernel.cu:91-165 dctQuantizationParallel, flattened:
+ * blocks = nb x 64 int32 pixels 0..255 (NOT level shifted, row-major 8x8),
+ * out = nb x 64 float quantised coefficients, natural order, integer valued,
+ * never -0.  HOST pointers. */
+int jpegamd_fdct_quant_blocks(const int32_t *blocks, size_t nb, const int32_t q[64], float *out);
+/* kernel.cuh:9-10 / kernel.cu:217-289 dequantizeInverseDCTParallel, flattened:
+ * coef = nb x 64 float quantised coefficients in natural order,
+ * out = nb x 64 int32 = IDCT + 128, UNCLAMPED (the caller clamps,
+ * encode_decode.cpp:808).  HOST pointers. */
+int jpegamd_dequant_idct_blocks(const float *coef, size_t nb, const int32_t q[64], int32_t *out);
+/* the same two on DEVICE pointers */
+int jpegamd_fdct_quant_blocks_dev(const int32_t *d_blocks, size_t nb, const int32_t q[64],
+                                  float *d_out, void *stream);
+int jpegamd_dequant_idct_blocks_dev(const float *d_coef, size_t nb, const int32_t q[64],
+                                    int32_t *d_out, void *stream);
+
+/* ---- one plane ------------------------------------------------------------ */
+/* encodeChannelGPU up to and including zigzag_scan, encode_decode.cpp:720-743:
+ * extractBlocks (zero fill outside the plane, 233-258) -> level shift -> DCT ->
+ * quantise -> zigzag.  Any rows/cols >= 1.  d_coef_zz holds
+ * ceil(rows/8)*ceil(cols/8)*64 int16.  DEVICE pointers. */
+int jpegamd_encode_plane_dev(const uint8_t *d_plane, int rows, int cols, size_t stride,
+                             const int32_t q[64], int16_t *d_coef_zz, void *stream);
+/* decodeChannelGPU from inverse_zigzag on, encode_decode.cpp:784-818:
+ * dequantise -> IDCT -> +128 -> clamp -> scatter (samples outside the plane are
+ * dropped).  DEVICE pointers. */
+int jpegamd_decode_plane_dev(const int16_t *d_coef_zz, int rows, int cols, const int32_t q[64],
+                             uint8_t *d_plane, size_t stride, void *stream);
+
+/* ---- fused colour image ----------------------------------------------------- */
+/* RGB2YCbCr (encode_decode.cpp:39-75) + chromaSubsampling (117-152) + the three
+ * encodeChannelGPU transforms (720-743) of mainEncode (1327-1329) in ONE launch.
+ * d_coef_y: (rows/8)*(cols/8)*64 int16; d_coef_cb/cr: (rows/16)*(cols/16)*64. */
+int jpegamd_encode_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride,
+                             const int32_t q_luma[64], const int32_t q_chroma[64],
+                             int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr,
+                             void *stream);
+/* The three decodeChannelGPU transforms (encode_decode.cpp:784-818) of mainDecode
+ * (1365-1367) + upsampleChroma (154-173) + YCbCr2RGB (77-114) in ONE launch. */
+int jpegamd_decode_image_dev(const int16_t *d_coef_y, const int16_t *d_coef_cb,
+                             const int16_t *d_coef_cr, int rows, int cols,
+                             const int32_t q_luma[64], const int32_t q_chroma[64],
+                             uint8_t *d_bgr, size_t stride, void *stream);
+/* HOST-pointer forms of the two above (allocate, copy in, launch, copy out). */
+int jpegamd_encode_image(const uint8_t *bgr, int rows, int cols, size_t stride,
+                         const int32_t q_luma[64], const int32_t q_chroma[64],
+                         int16_t *coef_y, int16_t *coef_cb, int16_t *coef_cr);
+int jpegamd_decode_image(const int16_t *coef_y, const int16_t *coef_cb, const int16_t *coef_cr,
+                         int rows, int cols, const int32_t q_luma[64],
+                         const int32_t q_chroma[64], uint8_t *bgr, size_t stride);
+
+/* Times `iters` back-to-back launches of encode followed by decode on `stream`
+ * with HIP events recorded on that same stream; writes the mean milliseconds
+ * per launch of each kernel.  Used by bench.py for the roofline figures. */
+int jpegamd_time_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride,
+                           const int32_t q_luma[64], const int32_t q_chroma[64],
+                           int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr,
+                           uint8_t *d_bgr_out, int iters, void *stream,
+                           float *enc_ms, float *dec_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

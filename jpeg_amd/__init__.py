@@ -1,0 +1,9 @@
+"""jpeg_amd -- MI355X (gfx950) implementation of the Fulim13/jpeg block-transform
+hot path, behind the C ABI of include/jpeg_amd.h.  Python here is plumbing for
+tests and bench.py: device memory (torch), streams, torch.distributed."""
+from ._lib import JpegAmdError, load, LIB_PATH  # noqa: F401
+from .api import (  # noqa: F401
+    quality_tables, analysis_tables, init,
+    encode_image, decode_image, encode_plane, decode_plane,
+    fdct_quant_blocks, dequant_idct_blocks, time_image, ZIGZAG,
+)

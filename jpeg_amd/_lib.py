@@ -1,0 +1,66 @@
+"""ctypes loader for libjpeg_amd.so (the C ABI of include/jpeg_amd.h).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is
+usable, loading or init raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpeg_amd.so")
+
+_c = ctypes
+_u8p, _i16p, _i32p, _f32p = (_c.POINTER(t) for t in (_c.c_uint8, _c.c_int16, _c.c_int32, _c.c_float))
+
+# name -> argtypes; every function returns int except last_error
+SIGNATURES = {
+    "jpegamd_init": [_c.c_int],
+    "jpegamd_abi_version": [],
+    "jpegamd_fdct_quant_blocks": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p],
+    "jpegamd_dequant_idct_blocks": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p],
+    "jpegamd_fdct_quant_blocks_dev": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p],
+    "jpegamd_dequant_idct_blocks_dev": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p],
+    "jpegamd_encode_plane_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p],
+    "jpegamd_decode_plane_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p],
+    "jpegamd_encode_image_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                                 _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p],
+    "jpegamd_decode_image_dev": [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
+                                 _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p],
+    "jpegamd_encode_image": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                             _c.c_void_p, _c.c_void_p, _c.c_void_p],
+    "jpegamd_decode_image": [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
+                             _c.c_void_p, _c.c_void_p, _c.c_size_t],
+    "jpegamd_time_image_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                               _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
+                               _c.POINTER(_c.c_float), _c.POINTER(_c.c_float)],
+}
+
+_lib = None
+
+
+class JpegAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JpegAmdError(
+                f"{LIB_PATH} is missing: build it with `make -C jpeg_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = _c.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _c.c_int
+        lib.jpegamd_last_error.argtypes = []
+        lib.jpegamd_last_error.restype = _c.c_char_p
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise JpegAmdError(load().jpegamd_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,164 @@
+"""Thin Python face of the C ABI (include/jpeg_amd.h).
+
+Names follow the reference: quality tables as main.cpp builds them, planes,
+blocks, zigzag coefficient planes.  Every compute call goes through
+libjpeg_amd.so; nothing here computes pixels or coefficients on the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+# scan position i holds natural index ZIGZAG[i] (encode_decode.cpp:312-348)
+ZIGZAG = np.array([
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63], dtype=np.int64)
+
+_BASE_LUMA = np.array([  # main.cpp:2-10
+    16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
+    14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+    18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.int64)
+_BASE_CHROMA = np.array([  # main.cpp:12-20
+    17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+    24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.int64)
+_ANALYSIS_HI_LUMA = np.array([  # analysis.cpp:45-54
+    3, 2, 2, 3, 5, 8, 10, 12, 2, 2, 3, 4, 5, 12, 12, 11,
+    3, 3, 3, 5, 8, 11, 14, 11, 3, 3, 4, 6, 10, 17, 16, 12,
+    4, 4, 7, 11, 14, 22, 21, 15, 5, 7, 11, 13, 16, 12, 23, 18,
+    10, 13, 16, 17, 21, 24, 24, 21, 14, 18, 19, 20, 22, 20, 20, 20], dtype=np.int64)
+_ANALYSIS_HI_CHROMA = np.array([  # analysis.cpp:56-65
+    11, 12, 14, 19, 26, 58, 60, 55, 12, 18, 21, 28, 32, 57, 59, 56,
+    14, 21, 25, 30, 59, 59, 59, 59, 19, 28, 30, 59, 59, 59, 59, 59,
+    26, 32, 59, 59, 59, 59, 59, 59, 58, 57, 59, 59, 59, 59, 59, 59,
+    60, 59, 59, 59, 59, 59, 59, 59, 55, 56, 59, 59, 59, 59, 59, 59], dtype=np.int64)
+
+
+def quality_tables(quality):
+    """main.cpp:51-80: (luma, chroma) int32[64] for quality 1..100."""
+    quality = int(quality)
+    if not 1 <= quality <= 100:
+        raise ValueError("Quality must be between 1 and 100")  # main.cpp:36-39
+    sf = 5000 // quality if quality < 50 else 200 - quality * 2
+    scale = lambda t: np.clip((t * sf + 50) // 100, 1, 255).astype(np.int32)
+    return scale(_BASE_LUMA), scale(_BASE_CHROMA)
+
+
+def analysis_tables(quality):
+    """analysis.cpp:43-90: the fixed (unscaled) table pairs."""
+    hi = int(quality) >= 90
+    return ((_ANALYSIS_HI_LUMA if hi else _BASE_LUMA).astype(np.int32),
+            (_ANALYSIS_HI_CHROMA if hi else _BASE_CHROMA).astype(np.int32))
+
+
+def init(device=0):
+    _lib.check(_lib.load().jpegamd_init(int(device)))
+
+
+def _q(t):
+    t = np.ascontiguousarray(np.asarray(t, dtype=np.int32).reshape(64))
+    return t, t.ctypes.data
+
+
+def _stream(stream):
+    if stream is None:
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(int(stream))
+
+
+def _dev(t, dtype, what):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise TypeError(f"{what}: expected a contiguous {dtype} tensor on the GPU")
+    return t.data_ptr()
+
+
+def encode_image(bgr, q_luma, q_chroma, out=None, stream=None):
+    """bgr: cuda uint8 [rows, cols, 3] -> (coef_y, coef_cb, coef_cr) cuda int16
+    [blocks, 64] in zigzag order (jpegamd_encode_image_dev)."""
+    import torch
+    rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
+    src = _dev(bgr, torch.uint8, "encode_image")
+    if out is None:
+        nby, nbc = (rows // 8) * (cols // 8), (rows // 16) * (cols // 16)
+        out = tuple(torch.empty((n, 64), dtype=torch.int16, device=bgr.device) for n in (nby, nbc, nbc))
+    ql, pl = _q(q_luma)
+    qc, pc = _q(q_chroma)
+    _lib.check(_lib.load().jpegamd_encode_image_dev(
+        src, rows, cols, cols * 3, pl, pc,
+        _dev(out[0], torch.int16, "coef_y"), _dev(out[1], torch.int16, "coef_cb"),
+        _dev(out[2], torch.int16, "coef_cr"), _stream(stream)))
+    return out
+
+
+def decode_image(coef_y, coef_cb, coef_cr, rows, cols, q_luma, q_chroma, out=None, stream=None):
+    """inverse of encode_image -> cuda uint8 [rows, cols, 3] (jpegamd_decode_image_dev)."""
+    import torch
+    if out is None:
+        out = torch.empty((rows, cols, 3), dtype=torch.uint8, device=coef_y.device)
+    ql, pl = _q(q_luma)
+    qc, pc = _q(q_chroma)
+    _lib.check(_lib.load().jpegamd_decode_image_dev(
+        _dev(coef_y, torch.int16, "coef_y"), _dev(coef_cb, torch.int16, "coef_cb"),
+        _dev(coef_cr, torch.int16, "coef_cr"), int(rows), int(cols), pl, pc,
+        _dev(out, torch.uint8, "bgr"), int(cols) * 3, _stream(stream)))
+    return out
+
+
+def encode_plane(plane, q, stream=None):
+    """plane: cuda uint8 [rows, cols] (any size) -> cuda int16 [blocks, 64] zigzag."""
+    import torch
+    rows, cols = int(plane.shape[0]), int(plane.shape[1])
+    nb = ((rows + 7) // 8) * ((cols + 7) // 8)
+    out = torch.empty((nb, 64), dtype=torch.int16, device=plane.device)
+    qq, pq = _q(q)
+    _lib.check(_lib.load().jpegamd_encode_plane_dev(
+        _dev(plane, torch.uint8, "plane"), rows, cols, cols, pq, out.data_ptr(), _stream(stream)))
+    return out
+
+
+def decode_plane(coef, rows, cols, q, stream=None):
+    import torch
+    out = torch.zeros((rows, cols), dtype=torch.uint8, device=coef.device)  # Mat::zeros, :793
+    qq, pq = _q(q)
+    _lib.check(_lib.load().jpegamd_decode_plane_dev(
+        _dev(coef, torch.int16, "coef"), int(rows), int(cols), pq, out.data_ptr(), int(cols), _stream(stream)))
+    return out
+
+
+def fdct_quant_blocks(blocks, q):
+    """kernel.cuh dctQuantizationParallel on flat host arrays: int32 [nb, 64] -> float32 [nb, 64]."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 64)
+    out = np.empty(blocks.shape, dtype=np.float32)
+    qq, pq = _q(q)
+    _lib.check(_lib.load().jpegamd_fdct_quant_blocks(blocks.ctypes.data, blocks.shape[0], pq, out.ctypes.data))
+    return out
+
+
+def dequant_idct_blocks(coef, q):
+    """kernel.cuh dequantizeInverseDCTParallel on flat host arrays: float32 [nb, 64] -> int32 [nb, 64]."""
+    coef = np.ascontiguousarray(coef, dtype=np.float32).reshape(-1, 64)
+    out = np.empty(coef.shape, dtype=np.int32)
+    qq, pq = _q(q)
+    _lib.check(_lib.load().jpegamd_dequant_idct_blocks(coef.ctypes.data, coef.shape[0], pq, out.ctypes.data))
+    return out
+
+
+def time_image(bgr, coefs, bgr_out, q_luma, q_chroma, iters, stream=None):
+    """HIP-event timing of `iters` encode launches then `iters` decode launches
+    on the stream they run on; returns (enc_ms, dec_ms) per launch."""
+    import torch
+    rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
+    ql, pl = _q(q_luma)
+    qc, pc = _q(q_chroma)
+    e, d = ctypes.c_float(0), ctypes.c_float(0)
+    _lib.check(_lib.load().jpegamd_time_image_dev(
+        _dev(bgr, torch.uint8, "bgr"), rows, cols, cols * 3, pl, pc,
+        coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
+        _dev(bgr_out, torch.uint8, "bgr_out"), int(iters), _stream(stream),
+        ctypes.byref(e), ctypes.byref(d)))
+    return e.value, d.value

@@ -1,0 +1,832 @@
+// jpeg_kernels.hip -- gfx950 (MI355X, CDNA4) kernels and the C ABI of
+// include/jpeg_amd.h.  Written for wave64 / 160 KiB LDS; there is no other
+// target and no CPU fallback.
+//
+// Work decomposition (DESIGN.md has the long form):
+//   * one LANE owns one 8x8 block for the transform stage: 64 samples live in
+//     VGPRs, both 1-D passes and the zigzag are pure register renaming -- no
+//     cross-lane traffic, no transposes.
+//   * one WAVE owns a 512 x 16 pixel tile (32 MCUs: 128 Y + 32 Cb + 32 Cr
+//     blocks = three 64-lane transform rounds) and shares nothing with other
+//     waves: only wave-level LDS ordering, never a workgroup barrier.
+//   * global traffic is always lane-contiguous: 12 B/lane BGR rows (768 B per
+//     wave instruction) and 16 B/lane coefficient chunks (1 KiB per wave
+//     instruction, staged through LDS so that each block's 128 B stay whole).
+//
+// Arithmetic lives in jpeg_math.h (shared with the CPU model the tests check
+// against the oracle).  Build with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/jpeg_amd.h"
+#include "jpeg_math.h"
+
+namespace {
+
+// ------------------------------------------------------------------ constants
+struct QuantConsts {
+    float q[64];  // (float)Q, natural order
+    float rq[64]; // RN(1/Q)
+};
+struct QuantPair {
+    QuantConsts t[2]; // [0] luma, [1] chroma
+};
+
+// zz position i holds natural index kZZ[i] (encode_decode.cpp:312-348)
+__device__ constexpr uint8_t kZZ[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+constexpr int kWaveTileW = 512;      // pixels per wave tile, horizontally
+constexpr int kStagePitch = 144;     // bytes per staged block (128 + 16 pad: conflict-free b128)
+constexpr int kStageBytes = 64 * kStagePitch; // 9216
+constexpr int kChromaBytes = 2 * 8 * 256;     // Cb + Cr, 8 rows x 256 samples
+constexpr int kWaveLds = kStageBytes + kChromaBytes; // 13312
+constexpr int kWavesPerWg = 4;
+
+struct __attribute__((aligned(4))) U3 {
+    uint32_t a, b, c;
+};
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wave are issued and retired in order; this only
+    // stops the compiler from moving accesses across the hand-over point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int u3_byte(const U3 &v, int idx)
+{
+    uint32_t w = idx < 4 ? v.a : (idx < 8 ? v.b : v.c);
+    return (int)((w >> ((idx & 3) * 8)) & 0xFFu);
+}
+
+// ------------------------------------------------------------ transform stage
+// v: 64 pixel values (row-major).  Returns quantised coefficients in v's place
+// as ints, natural order.
+__device__ __forceinline__ void block_fdct_quant(float (&v)[64], int (&qv)[64], const QuantConsts &qc)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        jm_fdct8<1, true>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3],
+                          v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        jm_fdct8<100, false>(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
+                             v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+        qv[i] = jm_snap_quant(v[i], qc.q[i], qc.rq[i]);
+}
+
+// v: 64 dequantised coefficients (natural order) -> pixel values + 128 (unclamped)
+__device__ __forceinline__ void block_idct(float (&v)[64], int (&px)[64])
+{
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        jm_idct8(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
+                 v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        jm_idct8(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3],
+                 v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+        px[i] = jm_round_pixel(v[i]);
+}
+
+// quantised block -> 128 bytes in zigzag order at stage + lane*144
+__device__ __forceinline__ void stage_write_zigzag(const int (&qv)[64], uint8_t *stage, int lane)
+{
+    uint4 *dst = reinterpret_cast<uint4 *>(stage + lane * kStagePitch);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i = (k * 4 + j) * 2;
+            w[j] = ((uint32_t)qv[kZZ[i]] & 0xFFFFu) | ((uint32_t)qv[kZZ[i + 1]] << 16);
+        }
+        dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// 128 staged bytes (zigzag int16) -> dequantised floats in natural order
+__device__ __forceinline__ void stage_read_dequant(const uint8_t *stage, int lane, float (&v)[64],
+                                                   const QuantConsts &qc)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(stage + lane * kStagePitch);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint4 d = src[k];
+        uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i = (k * 4 + j) * 2;
+            int lo = (int)(int16_t)(w[j] & 0xFFFFu);
+            int hi = (int)w[j] >> 16;
+            v[kZZ[i]] = (float)lo * qc.q[kZZ[i]];         // encode_decode.cpp:564 / kernel.cu:175
+            v[kZZ[i + 1]] = (float)hi * qc.q[kZZ[i + 1]];
+        }
+    }
+}
+
+// ------------------------------------------------------------- fused encoder
+// grid: one wave per 512x16 tile, 4 waves per workgroup.
+__global__ __launch_bounds__(256) void encode_image_kernel(
+    const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
+    int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
+    int tiles_x, int n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kWaveLds];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * kWavesPerWg + wave;
+    if (tile >= n_tiles)
+        return; // whole wave leaves together; nothing is shared between waves
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    uint8_t *stage = lds + wave * kWaveLds; // Y rows (8 x 512) alias the staging area
+    uint8_t *cbuf = stage + kStageBytes;    // Cb: 8 x 256, Cr: 8 x 256
+
+    const int x0 = tx * kWaveTileW;
+    const int bw_y = cols >> 3, bw_c = cols >> 4;
+
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+        if (it < 2) {
+            // ---- colour + 4:2:0 for tile rows 8*it .. 8*it+7 -----------------
+            const int row_base = ty * 16 + it * 8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int rp = t >> 1;
+                const int g = lane + 64 * (t & 1);
+                const int x = x0 + 4 * g;
+                if (x < cols) {
+                    const uint8_t *p0 = bgr + (size_t)(row_base + 2 * rp) * stride + (size_t)x * 3;
+                    U3 a = *reinterpret_cast<const U3 *>(p0);
+                    U3 b = *reinterpret_cast<const U3 *>(p0 + stride);
+                    uint32_t ya = 0, yb = 0;
+                    int cbs[2] = {0, 0}, crs[2] = {0, 0};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int y, cb, cr;
+                        jm_fwd_colour(u3_byte(a, 3 * j), u3_byte(a, 3 * j + 1), u3_byte(a, 3 * j + 2),
+                                      y, cb, cr);
+                        ya |= (uint32_t)y << (8 * j);
+                        cbs[j >> 1] += cb;
+                        crs[j >> 1] += cr;
+                        jm_fwd_colour(u3_byte(b, 3 * j), u3_byte(b, 3 * j + 1), u3_byte(b, 3 * j + 2),
+                                      y, cb, cr);
+                        yb |= (uint32_t)y << (8 * j);
+                        cbs[j >> 1] += cb;
+                        crs[j >> 1] += cr;
+                    }
+                    // chromaSubsampling: truncating mean of the quad (:139-149)
+                    uint16_t cbp = (uint16_t)((cbs[0] >> 2) | ((cbs[1] >> 2) << 8));
+                    uint16_t crp = (uint16_t)((crs[0] >> 2) | ((crs[1] >> 2) << 8));
+                    *reinterpret_cast<uint32_t *>(stage + (2 * rp) * 512 + 4 * g) = ya;
+                    *reinterpret_cast<uint32_t *>(stage + (2 * rp + 1) * 512 + 4 * g) = yb;
+                    const int crow = it * 4 + rp;
+                    *reinterpret_cast<uint16_t *>(cbuf + crow * 256 + 2 * g) = cbp;
+                    *reinterpret_cast<uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g) = crp;
+                }
+            }
+        }
+        wave_lds_fence();
+
+        // ---- transform: lane = block ---------------------------------------
+        const bool luma = it < 2;
+        const uint8_t *src = luma ? stage + lane * 8 : cbuf + (lane >> 5) * 2048 + (lane & 31) * 8;
+        const int pitch = luma ? 512 : 256;
+        const int bcol = luma ? tx * 64 + lane : tx * 32 + (lane & 31);
+        const bool valid = bcol < (luma ? bw_y : bw_c);
+        int qv[64];
+        if (valid) {
+            float v[64];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint2 d = *reinterpret_cast<const uint2 *>(src + r * pitch);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[r * 8 + j] = (float)((d.x >> (8 * j)) & 0xFFu);
+                    v[r * 8 + 4 + j] = (float)((d.y >> (8 * j)) & 0xFFu);
+                }
+            }
+            block_fdct_quant(v, qv, qp.t[luma ? 0 : 1]);
+        }
+        wave_lds_fence(); // every lane has its pixels: the Y rows may be overwritten
+        if (valid)
+            stage_write_zigzag(qv, stage, lane);
+        wave_lds_fence();
+
+        // ---- coalesced store: 64 blocks x 128 B = 8 x (64 lanes x 16 B) ------
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = k * 64 + lane;
+            const int b = j >> 3, part = j & 7;
+            int16_t *dst;
+            bool ok;
+            if (luma) {
+                ok = tx * 64 + b < bw_y;
+                dst = coef_y + ((size_t)(ty * 2 + it) * bw_y + tx * 64 + b) * 64;
+            } else {
+                ok = tx * 32 + (b & 31) < bw_c;
+                dst = (b >= 32 ? coef_cr : coef_cb) + ((size_t)ty * bw_c + tx * 32 + (b & 31)) * 64;
+            }
+            if (ok) {
+                uint4 d = *reinterpret_cast<const uint4 *>(stage + b * kStagePitch + part * 16);
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(dst) + part * 16) = d;
+            }
+        }
+        wave_lds_fence(); // staging area is free again
+    }
+}
+
+// ------------------------------------------------------------- fused decoder
+__global__ __launch_bounds__(256) void decode_image_kernel(
+    const int16_t *__restrict__ coef_y, const int16_t *__restrict__ coef_cb,
+    const int16_t *__restrict__ coef_cr, int rows, int cols, QuantPair qp,
+    uint8_t *__restrict__ bgr, size_t stride, int tiles_x, int n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kWaveLds];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * kWavesPerWg + wave;
+    if (tile >= n_tiles)
+        return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    uint8_t *stage = lds + wave * kWaveLds;
+    uint8_t *cbuf = stage + kStageBytes;
+    const int x0 = tx * kWaveTileW;
+    const int bw_y = cols >> 3, bw_c = cols >> 4;
+
+    // it = 0: the tile's 32 Cb + 32 Cr blocks; it = 1, 2: its two rows of 64 Y blocks
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+        const bool luma = it > 0;
+        // ---- coalesced load of 64 blocks x 128 B into the staging area -------
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = k * 64 + lane;
+            const int b = j >> 3, part = j & 7;
+            const int16_t *src;
+            bool ok;
+            if (luma) {
+                ok = tx * 64 + b < bw_y;
+                src = coef_y + ((size_t)(ty * 2 + it - 1) * bw_y + tx * 64 + b) * 64;
+            } else {
+                ok = tx * 32 + (b & 31) < bw_c;
+                src = (b >= 32 ? coef_cr : coef_cb) + ((size_t)ty * bw_c + tx * 32 + (b & 31)) * 64;
+            }
+            if (ok) {
+                uint4 d = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(src) + part * 16);
+                *reinterpret_cast<uint4 *>(stage + b * kStagePitch + part * 16) = d;
+            }
+        }
+        wave_lds_fence();
+
+        // ---- transform: lane = block ---------------------------------------
+        const int bcol = luma ? tx * 64 + lane : tx * 32 + (lane & 31);
+        const bool valid = bcol < (luma ? bw_y : bw_c);
+        int px[64];
+        if (valid) {
+            float v[64];
+            stage_read_dequant(stage, lane, v, qp.t[luma ? 0 : 1]);
+            block_idct(v, px);
+        }
+        wave_lds_fence(); // staged coefficients consumed: Y rows may overwrite them
+        if (valid) {
+            uint8_t *dst = luma ? stage + lane * 8 : cbuf + (lane >> 5) * 2048 + (lane & 31) * 8;
+            const int pitch = luma ? 512 : 256;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // std::clamp(block[i][j], 0, 255), encode_decode.cpp:808
+                    lo |= (uint32_t)jm_clamp255(px[r * 8 + j]) << (8 * j);
+                    hi |= (uint32_t)jm_clamp255(px[r * 8 + 4 + j]) << (8 * j);
+                }
+                *reinterpret_cast<uint2 *>(dst + r * pitch) = make_uint2(lo, hi);
+            }
+        }
+        wave_lds_fence();
+
+        if (luma) {
+            // ---- upsample + YCbCr2RGB for tile rows 8*(it-1) .. +7 ------------
+            const int row_base = ty * 16 + (it - 1) * 8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int rp = t >> 1;
+                const int g = lane + 64 * (t & 1);
+                const int x = x0 + 4 * g;
+                if (x < cols) {
+                    uint32_t ya = *reinterpret_cast<const uint32_t *>(stage + (2 * rp) * 512 + 4 * g);
+                    uint32_t yb = *reinterpret_cast<const uint32_t *>(stage + (2 * rp + 1) * 512 + 4 * g);
+                    const int crow = (it - 1) * 4 + rp;
+                    uint32_t cbp = *reinterpret_cast<const uint16_t *>(cbuf + crow * 256 + 2 * g);
+                    uint32_t crp = *reinterpret_cast<const uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g);
+                    uint8_t oa[12], ob[12];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        // upsampleChroma: (i/2, j/2), encode_decode.cpp:165-170
+                        const int cb = (int)((cbp >> (8 * h)) & 0xFFu), cr = (int)((crp >> (8 * h)) & 0xFFu);
+                        const JmChromaTerm ct = jm_inv_chroma(cb, cr);
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * h + jj;
+                            int o0, o1, o2;
+                            jm_inv_colour((int)((ya >> (8 * j)) & 0xFFu), cb, cr, ct, o0, o1, o2);
+                            oa[3 * j] = (uint8_t)o0, oa[3 * j + 1] = (uint8_t)o1, oa[3 * j + 2] = (uint8_t)o2;
+                            jm_inv_colour((int)((yb >> (8 * j)) & 0xFFu), cb, cr, ct, o0, o1, o2);
+                            ob[3 * j] = (uint8_t)o0, ob[3 * j + 1] = (uint8_t)o1, ob[3 * j + 2] = (uint8_t)o2;
+                        }
+                    }
+                    U3 wa, wb;
+                    wa.a = oa[0] | (oa[1] << 8) | (oa[2] << 16) | ((uint32_t)oa[3] << 24);
+                    wa.b = oa[4] | (oa[5] << 8) | (oa[6] << 16) | ((uint32_t)oa[7] << 24);
+                    wa.c = oa[8] | (oa[9] << 8) | (oa[10] << 16) | ((uint32_t)oa[11] << 24);
+                    wb.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | ((uint32_t)ob[3] << 24);
+                    wb.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | ((uint32_t)ob[7] << 24);
+                    wb.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | ((uint32_t)ob[11] << 24);
+                    uint8_t *p0 = bgr + (size_t)(row_base + 2 * rp) * stride + (size_t)x * 3;
+                    *reinterpret_cast<U3 *>(p0) = wa;
+                    *reinterpret_cast<U3 *>(p0 + stride) = wb;
+                }
+            }
+            wave_lds_fence(); // Y rows consumed before the next round stages over them
+        }
+    }
+}
+
+// --------------------------------------------------------------- plane level
+// lane = block, wave = 64 consecutive blocks of one block-row.  Any rows/cols:
+// samples outside the plane read as 0 before the level shift (extractBlocks,
+// encode_decode.cpp:242-251).
+__global__ __launch_bounds__(256) void encode_plane_kernel(
+    const uint8_t *__restrict__ plane, int rows, int cols, size_t stride, QuantConsts qc,
+    int16_t *__restrict__ coef, int bw, int groups_x, int n_groups)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kStageBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int grp = blockIdx.x * kWavesPerWg + wave;
+    if (grp >= n_groups)
+        return;
+    const int gx = grp % groups_x, by = grp / groups_x;
+    uint8_t *stage = lds + wave * kStageBytes;
+    const int bx = gx * 64 + lane;
+    const bool valid = bx < bw;
+    int qv[64];
+    if (valid) {
+        float v[64];
+        const int r0 = by * 8, c0 = bx * 8;
+        const bool interior = (r0 + 8 <= rows) && (c0 + 8 <= cols) && ((stride & 7) == 0) &&
+                              ((reinterpret_cast<uintptr_t>(plane) & 7) == 0);
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint2 d = *reinterpret_cast<const uint2 *>(plane + (size_t)(r0 + r) * stride + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[r * 8 + j] = (float)((d.x >> (8 * j)) & 0xFFu);
+                    v[r * 8 + 4 + j] = (float)((d.y >> (8 * j)) & 0xFFu);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    v[r * 8 + c] = (r0 + r < rows && c0 + c < cols)
+                                       ? (float)plane[(size_t)(r0 + r) * stride + c0 + c]
+                                       : 0.0f;
+        }
+        block_fdct_quant(v, qv, qc);
+        stage_write_zigzag(qv, stage, lane);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = k * 64 + lane;
+        const int b = j >> 3, part = j & 7;
+        if (gx * 64 + b < bw) {
+            uint4 d = *reinterpret_cast<const uint4 *>(stage + b * kStagePitch + part * 16);
+            uint8_t *dst = reinterpret_cast<uint8_t *>(coef + ((size_t)by * bw + gx * 64 + b) * 64);
+            *reinterpret_cast<uint4 *>(dst + part * 16) = d;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_plane_kernel(
+    const int16_t *__restrict__ coef, int rows, int cols, QuantConsts qc,
+    uint8_t *__restrict__ plane, size_t stride, int bw, int groups_x, int n_groups)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kStageBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int grp = blockIdx.x * kWavesPerWg + wave;
+    if (grp >= n_groups)
+        return;
+    const int gx = grp % groups_x, by = grp / groups_x;
+    uint8_t *stage = lds + wave * kStageBytes;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = k * 64 + lane;
+        const int b = j >> 3, part = j & 7;
+        if (gx * 64 + b < bw) {
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(coef + ((size_t)by * bw + gx * 64 + b) * 64);
+            *reinterpret_cast<uint4 *>(stage + b * kStagePitch + part * 16) =
+                *reinterpret_cast<const uint4 *>(src + part * 16);
+        }
+    }
+    wave_lds_fence();
+    const int bx = gx * 64 + lane;
+    if (bx < bw) {
+        float v[64];
+        int px[64];
+        stage_read_dequant(stage, lane, v, qc);
+        block_idct(v, px);
+        const int r0 = by * 8, c0 = bx * 8;
+        const bool interior = (r0 + 8 <= rows) && (c0 + 8 <= cols) && ((stride & 7) == 0) &&
+                              ((reinterpret_cast<uintptr_t>(plane) & 7) == 0);
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo |= (uint32_t)jm_clamp255(px[r * 8 + j]) << (8 * j);
+                    hi |= (uint32_t)jm_clamp255(px[r * 8 + 4 + j]) << (8 * j);
+                }
+                *reinterpret_cast<uint2 *>(plane + (size_t)(r0 + r) * stride + c0) = make_uint2(lo, hi);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (r0 + r < rows && c0 + c < cols) // encode_decode.cpp:805
+                        plane[(size_t)(r0 + r) * stride + c0 + c] = (uint8_t)jm_clamp255(px[r * 8 + c]);
+        }
+    }
+}
+
+// -------------------------------------------------------- legacy block level
+// kernel.cuh boundary: 32-bit in, 32-bit out, natural order.  lane = block.
+__global__ __launch_bounds__(256) void fdct_quant_blocks_kernel(
+    const int32_t *__restrict__ blocks, size_t nb, QuantConsts qc, float *__restrict__ out)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb)
+        return;
+    const int4 *src = reinterpret_cast<const int4 *>(blocks + b * 64);
+    float v[64];
+    int qv[64];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int4 d = src[k];
+        v[4 * k] = (float)d.x, v[4 * k + 1] = (float)d.y, v[4 * k + 2] = (float)d.z, v[4 * k + 3] = (float)d.w;
+    }
+    block_fdct_quant(v, qv, qc);
+    float4 *dst = reinterpret_cast<float4 *>(out + b * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        dst[k] = make_float4((float)qv[4 * k], (float)qv[4 * k + 1], (float)qv[4 * k + 2], (float)qv[4 * k + 3]);
+}
+
+__global__ __launch_bounds__(256) void dequant_idct_blocks_kernel(
+    const float *__restrict__ coef, size_t nb, QuantConsts qc, int32_t *__restrict__ out)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb)
+        return;
+    const float4 *src = reinterpret_cast<const float4 *>(coef + b * 64);
+    float v[64];
+    int px[64];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float4 d = src[k];
+        v[4 * k] = d.x * qc.q[4 * k], v[4 * k + 1] = d.y * qc.q[4 * k + 1];
+        v[4 * k + 2] = d.z * qc.q[4 * k + 2], v[4 * k + 3] = d.w * qc.q[4 * k + 3];
+    }
+    block_idct(v, px);
+    int4 *dst = reinterpret_cast<int4 *>(out + b * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        dst[k] = make_int4(px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]);
+}
+
+// ------------------------------------------------------------------ host side
+thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int make_consts(const int32_t q[64], QuantConsts &c, const char *what)
+{
+    if (!q)
+        return fail("%s: null quantisation table", what);
+    for (int i = 0; i < 64; ++i) {
+        if (q[i] < 1 || q[i] > 255)
+            return fail("%s: quantisation entry %d = %d outside 1..255", what, i, q[i]);
+        c.q[i] = (float)q[i];
+        c.rq[i] = 1.0f / (float)q[i];
+    }
+    return 0;
+}
+
+int check_image(const void *p, int rows, int cols, size_t stride, const char *what)
+{
+    if (!p)
+        return fail("%s: null image pointer", what);
+    if (rows <= 0 || cols <= 0 || (rows & 15) || (cols & 15))
+        return fail("%s: rows=%d cols=%d must be positive multiples of 16 "
+                    "(the reference resizes before this path, encode_decode.cpp:29-37)",
+                    what, rows, cols);
+    if (stride < (size_t)cols * 3 || (stride & 3) || (reinterpret_cast<uintptr_t>(p) & 3))
+        return fail("%s: stride=%zu must be >= 3*cols and, like the base pointer, 4-byte aligned", what, stride);
+    return 0;
+}
+
+struct DevBuf { // host-pointer entry points: per-call device memory
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int jpegamd_abi_version(void) { return 1; }
+
+const char *jpegamd_last_error(void) { return g_err; }
+
+int jpegamd_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail("no HIP device available (%s); libjpeg_amd has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail("device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return 0;
+}
+
+int jpegamd_encode_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride,
+                             const int32_t q_luma[64], const int32_t q_chroma[64],
+                             int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr, void *stream)
+{
+    QuantPair qp;
+    if (check_image(d_bgr, rows, cols, stride, "encode_image") || make_consts(q_luma, qp.t[0], "encode_image") ||
+        make_consts(q_chroma, qp.t[1], "encode_image"))
+        return 1;
+    if (!d_coef_y || !d_coef_cb || !d_coef_cr)
+        return fail("encode_image: null coefficient pointer");
+    const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
+    const int n_tiles = tiles_x * (rows / 16);
+    const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    hipLaunchKernelGGL(encode_image_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
+                       d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int jpegamd_decode_image_dev(const int16_t *d_coef_y, const int16_t *d_coef_cb, const int16_t *d_coef_cr,
+                             int rows, int cols, const int32_t q_luma[64], const int32_t q_chroma[64],
+                             uint8_t *d_bgr, size_t stride, void *stream)
+{
+    QuantPair qp;
+    if (check_image(d_bgr, rows, cols, stride, "decode_image") || make_consts(q_luma, qp.t[0], "decode_image") ||
+        make_consts(q_chroma, qp.t[1], "decode_image"))
+        return 1;
+    if (!d_coef_y || !d_coef_cb || !d_coef_cr)
+        return fail("decode_image: null coefficient pointer");
+    const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
+    const int n_tiles = tiles_x * (rows / 16);
+    const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    hipLaunchKernelGGL(decode_image_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
+                       d_coef_y, d_coef_cb, d_coef_cr, rows, cols, qp, d_bgr, stride, tiles_x, n_tiles);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int jpegamd_encode_plane_dev(const uint8_t *d_plane, int rows, int cols, size_t stride,
+                             const int32_t q[64], int16_t *d_coef_zz, void *stream)
+{
+    QuantConsts qc;
+    if (make_consts(q, qc, "encode_plane"))
+        return 1;
+    if (!d_plane || !d_coef_zz || rows <= 0 || cols <= 0 || stride < (size_t)cols)
+        return fail("encode_plane: bad arguments (rows=%d cols=%d stride=%zu)", rows, cols, stride);
+    const int bw = (cols + 7) / 8, bh = (rows + 7) / 8;
+    const int groups_x = (bw + 63) / 64;
+    const long n_groups = (long)groups_x * bh;
+    const int grid = (int)((n_groups + kWavesPerWg - 1) / kWavesPerWg);
+    hipLaunchKernelGGL(encode_plane_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
+                       d_plane, rows, cols, stride, qc, d_coef_zz, bw, groups_x, (int)n_groups);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int jpegamd_decode_plane_dev(const int16_t *d_coef_zz, int rows, int cols, const int32_t q[64],
+                             uint8_t *d_plane, size_t stride, void *stream)
+{
+    QuantConsts qc;
+    if (make_consts(q, qc, "decode_plane"))
+        return 1;
+    if (!d_plane || !d_coef_zz || rows <= 0 || cols <= 0 || stride < (size_t)cols)
+        return fail("decode_plane: bad arguments (rows=%d cols=%d stride=%zu)", rows, cols, stride);
+    const int bw = (cols + 7) / 8, bh = (rows + 7) / 8;
+    const int groups_x = (bw + 63) / 64;
+    const long n_groups = (long)groups_x * bh;
+    const int grid = (int)((n_groups + kWavesPerWg - 1) / kWavesPerWg);
+    hipLaunchKernelGGL(decode_plane_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
+                       d_coef_zz, rows, cols, qc, d_plane, stride, bw, groups_x, (int)n_groups);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int jpegamd_fdct_quant_blocks_dev(const int32_t *d_blocks, size_t nb, const int32_t q[64], float *d_out,
+                                  void *stream)
+{
+    QuantConsts qc;
+    if (make_consts(q, qc, "fdct_quant_blocks"))
+        return 1;
+    if (nb == 0)
+        return 0;
+    if (!d_blocks || !d_out)
+        return fail("fdct_quant_blocks: null pointer");
+    if (nb > (size_t)0x7FFFFFFF * 64)
+        return fail("fdct_quant_blocks: nb=%zu too large", nb);
+    hipLaunchKernelGGL(fdct_quant_blocks_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_blocks, nb, qc, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int jpegamd_dequant_idct_blocks_dev(const float *d_coef, size_t nb, const int32_t q[64], int32_t *d_out,
+                                    void *stream)
+{
+    QuantConsts qc;
+    if (make_consts(q, qc, "dequant_idct_blocks"))
+        return 1;
+    if (nb == 0)
+        return 0;
+    if (!d_coef || !d_out)
+        return fail("dequant_idct_blocks: null pointer");
+    if (nb > (size_t)0x7FFFFFFF * 64)
+        return fail("dequant_idct_blocks: nb=%zu too large", nb);
+    hipLaunchKernelGGL(dequant_idct_blocks_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_coef, nb, qc, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int jpegamd_fdct_quant_blocks(const int32_t *blocks, size_t nb, const int32_t q[64], float *out)
+{
+    if (nb == 0)
+        return 0;
+    if (!blocks || !out)
+        return fail("fdct_quant_blocks: null pointer");
+    DevBuf in, res;
+    HIPCHK(hipMalloc(&in.p, nb * 64 * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&res.p, nb * 64 * sizeof(float)));
+    HIPCHK(hipMemcpy(in.p, blocks, nb * 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (jpegamd_fdct_quant_blocks_dev((const int32_t *)in.p, nb, q, (float *)res.p, nullptr))
+        return 1;
+    HIPCHK(hipMemcpy(out, res.p, nb * 64 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jpegamd_dequant_idct_blocks(const float *coef, size_t nb, const int32_t q[64], int32_t *out)
+{
+    if (nb == 0)
+        return 0;
+    if (!coef || !out)
+        return fail("dequant_idct_blocks: null pointer");
+    DevBuf in, res;
+    HIPCHK(hipMalloc(&in.p, nb * 64 * sizeof(float)));
+    HIPCHK(hipMalloc(&res.p, nb * 64 * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(in.p, coef, nb * 64 * sizeof(float), hipMemcpyHostToDevice));
+    if (jpegamd_dequant_idct_blocks_dev((const float *)in.p, nb, q, (int32_t *)res.p, nullptr))
+        return 1;
+    HIPCHK(hipMemcpy(out, res.p, nb * 64 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jpegamd_encode_image(const uint8_t *bgr, int rows, int cols, size_t stride,
+                         const int32_t q_luma[64], const int32_t q_chroma[64],
+                         int16_t *coef_y, int16_t *coef_cb, int16_t *coef_cr)
+{
+    if (!bgr || !coef_y || !coef_cb || !coef_cr)
+        return fail("encode_image: null pointer");
+    if (rows <= 0 || cols <= 0 || (rows & 15) || (cols & 15) || stride < (size_t)cols * 3)
+        return fail("encode_image: rows=%d cols=%d stride=%zu unsupported", rows, cols, stride);
+    const size_t dstride = (size_t)cols * 3; // packed on the device
+    const size_t ny = (size_t)rows * cols, nc = ny / 4;
+    DevBuf img, cy, cb, cr;
+    HIPCHK(hipMalloc(&img.p, dstride * rows));
+    HIPCHK(hipMalloc(&cy.p, ny * 2));
+    HIPCHK(hipMalloc(&cb.p, nc * 2));
+    HIPCHK(hipMalloc(&cr.p, nc * 2));
+    HIPCHK(hipMemcpy2D(img.p, dstride, bgr, stride, dstride, rows, hipMemcpyHostToDevice));
+    if (jpegamd_encode_image_dev((const uint8_t *)img.p, rows, cols, dstride, q_luma, q_chroma,
+                                 (int16_t *)cy.p, (int16_t *)cb.p, (int16_t *)cr.p, nullptr))
+        return 1;
+    HIPCHK(hipMemcpy(coef_y, cy.p, ny * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(coef_cb, cb.p, nc * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(coef_cr, cr.p, nc * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jpegamd_decode_image(const int16_t *coef_y, const int16_t *coef_cb, const int16_t *coef_cr,
+                         int rows, int cols, const int32_t q_luma[64], const int32_t q_chroma[64],
+                         uint8_t *bgr, size_t stride)
+{
+    if (!bgr || !coef_y || !coef_cb || !coef_cr)
+        return fail("decode_image: null pointer");
+    if (rows <= 0 || cols <= 0 || (rows & 15) || (cols & 15) || stride < (size_t)cols * 3)
+        return fail("decode_image: rows=%d cols=%d stride=%zu unsupported", rows, cols, stride);
+    const size_t dstride = (size_t)cols * 3;
+    const size_t ny = (size_t)rows * cols, nc = ny / 4;
+    DevBuf img, cy, cb, cr;
+    HIPCHK(hipMalloc(&img.p, dstride * rows));
+    HIPCHK(hipMalloc(&cy.p, ny * 2));
+    HIPCHK(hipMalloc(&cb.p, nc * 2));
+    HIPCHK(hipMalloc(&cr.p, nc * 2));
+    HIPCHK(hipMemcpy(cy.p, coef_y, ny * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(cb.p, coef_cb, nc * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(cr.p, coef_cr, nc * 2, hipMemcpyHostToDevice));
+    if (jpegamd_decode_image_dev((const int16_t *)cy.p, (const int16_t *)cb.p, (const int16_t *)cr.p, rows, cols,
+                                 q_luma, q_chroma, (uint8_t *)img.p, dstride, nullptr))
+        return 1;
+    HIPCHK(hipMemcpy2D(bgr, stride, img.p, dstride, dstride, rows, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jpegamd_time_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride,
+                           const int32_t q_luma[64], const int32_t q_chroma[64],
+                           int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr,
+                           uint8_t *d_bgr_out, int iters, void *stream, float *enc_ms, float *dec_ms)
+{
+    if (iters <= 0 || !enc_ms || !dec_ms)
+        return fail("time_image: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventCreate(&e2));
+    int rc = 0;
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters && !rc; ++i)
+        rc = jpegamd_encode_image_dev(d_bgr, rows, cols, stride, q_luma, q_chroma, d_coef_y, d_coef_cb,
+                                      d_coef_cr, stream);
+    HIPCHK(hipEventRecord(e1, s));
+    for (int i = 0; i < iters && !rc; ++i)
+        rc = jpegamd_decode_image_dev(d_coef_y, d_coef_cb, d_coef_cr, rows, cols, q_luma, q_chroma,
+                                      d_bgr_out, stride, stream);
+    HIPCHK(hipEventRecord(e2, s));
+    HIPCHK(hipEventSynchronize(e2));
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, e0, e1));
+    HIPCHK(hipEventElapsedTime(&b, e1, e2));
+    *enc_ms = a / iters;
+    *dec_ms = b / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    return rc;
+}
+
+} // extern "C"

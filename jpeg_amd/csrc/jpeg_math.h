@@ -1,0 +1,273 @@
+// jpeg_math.h -- the per-sample arithmetic of the gfx950 kernels, written so
+// that the same source compiles as device code (hipcc) and as plain host C++
+// (g++, for tests/kernel_math_model.cpp, which checks it against the oracle
+// exhaustively on the CPU).  Compile with -ffp-contract=off: every fused
+// multiply-add below is an explicit jm_fma().
+//
+// What each piece stands in for (reference = /root/reference):
+//   jm_fwd_colour   RGB2YCbCr            encode_decode.cpp:39-75
+//   jm_inv_*        YCbCr2RGB            encode_decode.cpp:77-114
+//   jm_fdct8 x2     dct                  encode_decode.cpp:260-287
+//   jm_snap_quant   dct's 2-decimal snap (284) + quantize (300-310)
+//   jm_idct8 x2     idct                 encode_decode.cpp:569-594
+//   jm_round_pixel  round(0.25*sum) (591), tie handling see below
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define JM_HD __host__ __device__ __forceinline__
+#else
+#define JM_HD static inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define jm_fma(a, b, c) __builtin_fmaf((a), (b), (c))
+#define jm_trunc(a) __builtin_truncf(a)
+#define jm_rint(a) __builtin_rintf(a)
+#define jm_copysign(a, b) __builtin_copysignf((a), (b))
+#else
+#include <math.h>
+#define jm_fma(a, b, c) fmaf((a), (b), (c))
+#define jm_trunc(a) truncf(a)
+#define jm_rint(a) rintf(a)
+#define jm_copysign(a, b) copysignf((a), (b))
+#endif
+
+// ---------------------------------------------------------------------------
+// Exact roundf() (half away from zero) for |v| < 2^22: adding the largest
+// float below 0.5 never carries a value that is below k+0.5 up to k+1, and
+// always carries k+0.5 itself.  Checked exhaustively in the model test.
+JM_HD float jm_round_half_away(float v)
+{
+    return jm_trunc(v + jm_copysign(0x1.fffffep-2f, v));
+}
+
+// ------------------------------------------------------------ forward colour
+// The reference evaluates  t = off + m0*p0 + m1*p1 + m2*p2  in double, one
+// rounding per operation, then round() half away.  With p integers the exact
+// value is a rational with denominator 1000 (Y) or 10000 (Cb, Cr), so unless
+// it is an exact x.5 tie the nearest integer is decided 1e-4 away from any
+// double rounding error (~1e-13): integer arithmetic gives the same answer.
+// Exact ties (about 1 pixel in 1000 for Y) depend on the double rounding
+// errors and are re-evaluated with the reference's own operation sequence.
+
+JM_HD double jm_round_half_away_f64(double t)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_trunc(t);
+    double d = t - r; // exact
+    if (__builtin_fabs(d) >= 0.5)
+        r += __builtin_copysign(1.0, t);
+    return r;
+#else
+    return round(t);
+#endif
+}
+
+// one channel, the reference's operation order (no contraction!)
+JM_HD int jm_fwd_colour_f64(int k, int p0, int p1, int p2)
+{
+    const double off = (k == 0) ? 0.0 : 128.0;
+    const double m0 = (k == 0) ? 0.299 : (k == 1) ? -0.1687 : 0.5;
+    const double m1 = (k == 0) ? 0.587 : (k == 1) ? -0.3313 : -0.4187;
+    const double m2 = (k == 0) ? 0.114 : (k == 1) ? 0.5 : -0.0813;
+    double t = off;
+    t = t + m0 * (double)p0;
+    t = t + m1 * (double)p1;
+    t = t + m2 * (double)p2;
+    t = jm_round_half_away_f64(t);
+    return (int)t & 0xFF; // static_cast<uchar>: 256 wraps to 0
+}
+
+// floor(n / 1000) for 0 <= n < 2^18 and floor(n / 10000) for 0 <= n < 2^22,
+// through one float fma (n is exact in float; the bias keeps exact multiples
+// on the right side of the truncation).  Checked over the full ranges.
+JM_HD uint32_t jm_div1000(uint32_t n)
+{
+    return (uint32_t)jm_fma((float)n, 1.0e-3f, 1.0f / 4096.0f);
+}
+JM_HD uint32_t jm_div10000(uint32_t n)
+{
+    return (uint32_t)jm_fma((float)n, 1.0e-4f, 3.0f / 65536.0f);
+}
+
+// p0,p1,p2 = the stored channel order (cv::imread's B,G,R; the reference
+// applies its "R,G,B" matrix to them as they come).
+JM_HD void jm_fwd_colour(int p0, int p1, int p2, int &y, int &cb, int &cr)
+{
+    uint32_t ny = (uint32_t)(299 * p0 + 587 * p1 + 114 * p2 + 500);
+    uint32_t nb = (uint32_t)(1285000 - 1687 * p0 - 3313 * p1 + 5000 * p2);
+    uint32_t nr = (uint32_t)(1285000 + 5000 * p0 - 4187 * p1 - 813 * p2);
+    uint32_t qy = jm_div1000(ny), qb = jm_div10000(nb), qr = jm_div10000(nr);
+    uint32_t ry = ny - qy * 1000u, rb = nb - qb * 10000u, rr = nr - qr * 10000u;
+    y = (int)qy;
+    cb = (int)(qb & 0xFFu);
+    cr = (int)(qr & 0xFFu);
+    uint32_t rmin = ry < rb ? ry : rb;
+    rmin = rmin < rr ? rmin : rr;
+    if (__builtin_expect(rmin == 0u, 0)) { // an exact .5 somewhere: ask the doubles
+        if (ry == 0u)
+            y = jm_fwd_colour_f64(0, p0, p1, p2);
+        if (rb == 0u)
+            cb = jm_fwd_colour_f64(1, p0, p1, p2);
+        if (rr == 0u)
+            cr = jm_fwd_colour_f64(2, p0, p1, p2);
+    }
+}
+
+// ------------------------------------------------------------ inverse colour
+// out_k = clamp(round(Y + m_k1*(Cb-128) + m_k2*(Cr-128))): Y is an integer, so
+// the rounding only concerns the chroma term, shared by the 2x2 pixels of one
+// chroma sample.  Same tie argument as above (denominators 1000 and 10^6).
+struct JmChromaTerm {
+    int d0, d1, d2; // rounded chroma contributions to channels 0,1,2
+    int tie;        // bit k set: channel k is an exact tie, use the doubles
+};
+
+JM_HD JmChromaTerm jm_inv_chroma(int cb, int cr)
+{
+    int b = cb - 128, r = cr - 128;
+    uint32_t n0 = (uint32_t)(1402 * r + 500 + 256000);
+    uint32_t n2 = (uint32_t)(1772 * b + 500 + 256000);
+    uint32_t n1 = (uint32_t)(-344136 * b - 714136 * r + 500000 + 256000000);
+    // plain integer divisions: once per chroma sample, not per pixel
+    uint32_t q0 = n0 / 1000u, q2 = n2 / 1000u, q1 = n1 / 1000000u;
+    JmChromaTerm t;
+    t.d0 = (int)q0 - 256;
+    t.d1 = (int)q1 - 256;
+    t.d2 = (int)q2 - 256;
+    t.tie = (n0 - q0 * 1000u == 0u ? 1 : 0) | (n1 - q1 * 1000000u == 0u ? 2 : 0) |
+            (n2 - q2 * 1000u == 0u ? 4 : 0);
+    return t;
+}
+
+JM_HD int jm_clamp255(int v)
+{
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// one channel, the reference's operation order
+JM_HD int jm_inv_colour_f64(int k, int y, int cb, int cr)
+{
+    const double m1 = (k == 0) ? 0.0 : (k == 1) ? -0.344136 : 1.772;
+    const double m2 = (k == 0) ? 1.402 : (k == 1) ? -0.714136 : 0.0;
+    double t = 0.0;
+    t = t + 1.0 * ((double)y - 0.0);
+    t = t + m1 * ((double)cb - 128.0);
+    t = t + m2 * ((double)cr - 128.0);
+    t = jm_round_half_away_f64(t);
+    t = t > 255.0 ? 255.0 : t;
+    t = t < 0.0 ? 0.0 : t;
+    return (int)t;
+}
+
+JM_HD void jm_inv_colour(int y, int cb, int cr, const JmChromaTerm &c, int &o0, int &o1, int &o2)
+{
+    o0 = jm_clamp255(y + c.d0);
+    o1 = jm_clamp255(y + c.d1);
+    o2 = jm_clamp255(y + c.d2);
+    if (__builtin_expect(c.tie != 0, 0)) {
+        if (c.tie & 1)
+            o0 = jm_inv_colour_f64(0, y, cb, cr);
+        if (c.tie & 2)
+            o1 = jm_inv_colour_f64(1, y, cb, cr);
+        if (c.tie & 4)
+            o2 = jm_inv_colour_f64(2, y, cb, cr);
+    }
+}
+
+// --------------------------------------------------------------- 8-point DCT
+// X_u = (c_u/2) sum_n x_n cos((2n+1)u*pi/16), even/odd split, all in f32.
+// Two passes give 0.25*cu*cv*sum of encode_decode.cpp:284.  S scales the
+// outputs (the second forward pass folds the *100/4... factor: see kernels).
+#define JM_A0 0.35355339059327376220 /* 1/(2*sqrt(2)) = cos(pi/4)/2 */
+#define JM_C1 0.49039264020161522456
+#define JM_C2 0.46193976625564337806
+#define JM_C3 0.41573480615127261854
+#define JM_C5 0.27778511650980111237
+#define JM_C6 0.19134171618254488586
+#define JM_C7 0.09754516100806413392
+
+// LEVEL: subtract the 128 level shift (recenterAroundZero, :289-298) -- it only
+// reaches the u=0 output, every other output is built from differences.
+template <int SNUM, bool LEVEL>
+JM_HD void jm_fdct8(float &x0, float &x1, float &x2, float &x3,
+                    float &x4, float &x5, float &x6, float &x7)
+{
+    constexpr double S = (double)SNUM;
+    constexpr float A0 = (float)(S * JM_A0), C1 = (float)(S * JM_C1), C2 = (float)(S * JM_C2),
+                    C3 = (float)(S * JM_C3), C5 = (float)(S * JM_C5), C6 = (float)(S * JM_C6),
+                    C7 = (float)(S * JM_C7);
+    float s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
+    float d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
+    float t0 = s0 + s3, t1 = s1 + s2, t2 = s0 - s3, t3 = s1 - s2;
+    x0 = LEVEL ? A0 * ((t0 + t1) - 1024.0f) : A0 * (t0 + t1);
+    x4 = A0 * (t0 - t1);
+    x2 = jm_fma(C2, t2, C6 * t3);
+    x6 = jm_fma(C6, t2, -(C2 * t3));
+    x1 = jm_fma(C7, d3, jm_fma(C5, d2, jm_fma(C3, d1, C1 * d0)));
+    x3 = jm_fma(-C5, d3, jm_fma(-C1, d2, jm_fma(-C7, d1, C3 * d0)));
+    x5 = jm_fma(C3, d3, jm_fma(C7, d2, jm_fma(-C1, d1, C5 * d0)));
+    x7 = jm_fma(-C1, d3, jm_fma(C3, d2, jm_fma(-C5, d1, C7 * d0)));
+}
+
+// x_n = sum_u (c_u/2) X_u cos((2n+1)u*pi/16)
+JM_HD void jm_idct8(float &x0, float &x1, float &x2, float &x3,
+                    float &x4, float &x5, float &x6, float &x7)
+{
+    constexpr float A0 = (float)JM_A0, C1 = (float)JM_C1, C2 = (float)JM_C2, C3 = (float)JM_C3,
+                    C5 = (float)JM_C5, C6 = (float)JM_C6, C7 = (float)JM_C7;
+    float p0 = A0 * (x0 + x4), p1 = A0 * (x0 - x4);
+    float r0 = jm_fma(C2, x2, C6 * x6), r1 = jm_fma(C6, x2, -(C2 * x6));
+    float e0 = p0 + r0, e3 = p0 - r0, e1 = p1 + r1, e2 = p1 - r1;
+    float o0 = jm_fma(C7, x7, jm_fma(C5, x5, jm_fma(C3, x3, C1 * x1)));
+    float o1 = jm_fma(-C5, x7, jm_fma(-C1, x5, jm_fma(-C7, x3, C3 * x1)));
+    float o2 = jm_fma(C3, x7, jm_fma(C7, x5, jm_fma(-C1, x3, C5 * x1)));
+    float o3 = jm_fma(-C1, x7, jm_fma(C3, x5, jm_fma(-C5, x3, C7 * x1)));
+    x0 = e0 + o0;
+    x7 = e0 - o0;
+    x1 = e1 + o1;
+    x6 = e1 - o1;
+    x2 = e2 + o2;
+    x5 = e2 - o2;
+    x3 = e3 + o3;
+    x4 = e3 - o3;
+}
+
+// ------------------------------------------------------------------ quantise
+// x100 = 100 * (0.25*cu*cv*sum) as produced by the two forward passes (the
+// second one scaled by 100).  Follows the reference bit for bit from there:
+//   r = round(x100)                       encode_decode.cpp:284 round(...*100)
+//   c = (float)(r / 100)                  :284  (/100, narrowed to float)
+//   v = c / (float)Q                      :306  IEEE float division
+//   q = roundf(v); -0 -> 0                :306-307
+// Both divisions are done as multiply + one Newton correction (q0 = a*y,
+// q = fma(fma(-b, q0, a), y, q0) with y = RN(1/b)), which is the correctly
+// rounded quotient for these operand ranges; the model test checks every
+// (r, Q) pair against real divisions.
+JM_HD float jm_div_by(float a, float b, float rcp_b)
+{
+    float q0 = a * rcp_b;
+    float rem = jm_fma(-b, q0, a);
+    return jm_fma(rem, rcp_b, q0);
+}
+
+JM_HD int jm_snap_quant(float x100, float q, float rcp_q)
+{
+    float r = jm_round_half_away(x100);
+    float c = jm_div_by(r, 100.0f, 0.01f);
+    float v = jm_div_by(c, q, rcp_q);
+    return (int)jm_round_half_away(v); // (int)(-0.0f) == 0
+}
+
+// ------------------------------------------------------------- pixel rounding
+// x = 0.25*sum of encode_decode.cpp:591 as produced by the two inverse passes.
+// The reference's accumulation makes exact x.5 ties (frequent for DC-only
+// chroma blocks) fall toward zero, because float(1/sqrt(2))^2 = 0.49999997;
+// a 1e-5 pull toward zero before round-to-nearest reproduces that
+// (SURVEY.md 8a-12).  Returns round(...) + 128, unclamped.
+JM_HD int jm_round_pixel(float x)
+{
+    float y = x - jm_copysign(1.0e-5f, x);
+    return (int)jm_rint(y) + 128;
+}

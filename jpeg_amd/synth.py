@@ -1,0 +1,48 @@
+"""Synthetic input images: integer-only generators, so the same
+seed gives the same bytes on the CPU and on the GPU.
+
+  photo : smooth two-octave value field + small triangular noise (realistic
+          sparsity after quantisation, ~5-8 non-zero coefficients per block)
+  noise : i.i.d. uniform bytes (dense coefficients, longest run-length output,
+          exercises the Cb/Cr = 256 wrap of encode_decode.cpp:67-70)
+  gray  : photo luminance replicated to B=G=R (what cv::imread makes of a
+          grayscale file: Y = g, Cb = Cr = 128)
+"""
+import torch
+
+_M32 = 0xFFFFFFFF
+
+
+def _hash(ix, iy, c, seed):
+    x = (ix * 0x1E3779B1 + iy * 0x05EBCA77 + c * 0x42B2AE3D + seed * 0x27D4EB2F) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x2C1B3C6D) & _M32
+    x = x ^ (x >> 12)
+    x = (x * 0x297A2D39) & _M32
+    return x ^ (x >> 15)
+
+
+def _octave(yy, xx, c, seed, cell):
+    gy, fy = yy // cell, yy % cell
+    gx, fx = xx // cell, xx % cell
+    g = lambda a, b: _hash(a, b, c, seed) & 255
+    top = (cell - fx) * g(gx, gy) + fx * g(gx + 1, gy)
+    bot = (cell - fx) * g(gx, gy + 1) + fx * g(gx + 1, gy + 1)
+    return ((cell - fy) * top + fy * bot) // (cell * cell)
+
+
+def synth_image(rows, cols, seed=0, kind="photo", device="cpu"):
+    """uint8 tensor [rows, cols, 3] in cv::imread channel order."""
+    yy = torch.arange(rows, dtype=torch.int64, device=device).view(rows, 1)
+    xx = torch.arange(cols, dtype=torch.int64, device=device).view(1, cols)
+    out = torch.empty((rows, cols, 3), dtype=torch.uint8, device=device)
+    for c in range(3):
+        ch = 0 if kind == "gray" else c
+        if kind == "noise":
+            v = _hash(xx, yy, c, seed + 77) & 255
+        else:
+            v = (3 * _octave(yy, xx, ch, seed, 64) + _octave(yy, xx, ch, seed + 1, 16)) // 4
+            h = _hash(xx, yy, ch, seed + 2)
+            v = v + (h & 7) + ((h >> 3) & 7) - 7
+        out[:, :, c] = v.clamp_(0, 255).to(torch.uint8)
+    return out

@@ -1,0 +1,139 @@
+// kernel_math_model.cpp -- host build of jpeg_amd/csrc/jpeg_math.h, the exact
+// per-sample arithmetic the gfx950 kernels execute (same source, g++ instead
+// of hipcc).  TEST INFRASTRUCTURE: lets the CPU-only suite check that
+// arithmetic against the oracle (exhaustively for colour, the divisions and
+// the rounding tricks) before anything runs on a GPU.  It is not a product
+// path and nothing in jpeg_amd/ loads it.
+#include "../../jpeg_amd/csrc/jpeg_math.h"
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+static const uint8_t kZigzag[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+extern "C" {
+
+// n interleaved 3-byte pixels -> interleaved Y,Cb,Cr
+void jmm_fwd_colour(const uint8_t *src, size_t n, uint8_t *dst)
+{
+    for (size_t i = 0; i < n; ++i) {
+        int y, cb, cr;
+        jm_fwd_colour(src[3 * i], src[3 * i + 1], src[3 * i + 2], y, cb, cr);
+        dst[3 * i] = (uint8_t)y;
+        dst[3 * i + 1] = (uint8_t)cb;
+        dst[3 * i + 2] = (uint8_t)cr;
+    }
+}
+
+void jmm_inv_colour(const uint8_t *src, size_t n, uint8_t *dst)
+{
+    for (size_t i = 0; i < n; ++i) {
+        JmChromaTerm c = jm_inv_chroma(src[3 * i + 1], src[3 * i + 2]);
+        int o0, o1, o2;
+        jm_inv_colour(src[3 * i], src[3 * i + 1], src[3 * i + 2], c, o0, o1, o2);
+        dst[3 * i] = (uint8_t)o0;
+        dst[3 * i + 1] = (uint8_t)o1;
+        dst[3 * i + 2] = (uint8_t)o2;
+    }
+}
+
+// nb blocks of 64 pixel values (0..255, not level shifted) -> quantised
+// coefficients, natural order, exactly as the kernels' block stage does.
+void jmm_fdct_quant_blocks(const int32_t *px, size_t nb, const int32_t *q, int32_t *out)
+{
+    float qf[64], rq[64];
+    for (int i = 0; i < 64; ++i) {
+        qf[i] = (float)q[i];
+        rq[i] = 1.0f / qf[i];
+    }
+    for (size_t b = 0; b < nb; ++b) {
+        float v[64];
+        for (int i = 0; i < 64; ++i)
+            v[i] = (float)px[b * 64 + i];
+        for (int r = 0; r < 8; ++r) // rows: out index = horizontal frequency
+            jm_fdct8<1, true>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3],
+                              v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+        for (int c = 0; c < 8; ++c) // columns, scaled by 100
+            jm_fdct8<100, false>(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
+                                 v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
+        for (int i = 0; i < 64; ++i)
+            out[b * 64 + i] = jm_snap_quant(v[i], qf[i], rq[i]);
+    }
+}
+
+// nb blocks of quantised coefficients (natural order) -> pixels + 128, unclamped
+void jmm_dequant_idct_blocks(const int32_t *coef, size_t nb, const int32_t *q, int32_t *out)
+{
+    for (size_t b = 0; b < nb; ++b) {
+        float v[64];
+        for (int i = 0; i < 64; ++i)
+            v[i] = (float)coef[b * 64 + i] * (float)q[i];
+        for (int c = 0; c < 8; ++c)
+            jm_idct8(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
+                     v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
+        for (int r = 0; r < 8; ++r)
+            jm_idct8(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3],
+                     v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+        for (int i = 0; i < 64; ++i)
+            out[b * 64 + i] = jm_round_pixel(v[i]);
+    }
+}
+
+const uint8_t *jmm_zigzag(void) { return kZigzag; }
+
+// ---- exhaustive self-checks of the arithmetic shortcuts; return #failures --
+
+// jm_div1000 / jm_div10000 over their whole input ranges
+long jmm_check_const_div(void)
+{
+    long bad = 0;
+    for (uint32_t n = 0; n < (1u << 18); ++n)
+        bad += jm_div1000(n) != n / 1000u;
+    for (uint32_t n = 0; n < (1u << 22); ++n)
+        bad += jm_div10000(n) != n / 10000u;
+    return bad;
+}
+
+// jm_round_half_away == roundf on every float with |v| < 2^22 (+ both zeros)
+long jmm_check_round(void)
+{
+    long bad = 0;
+    for (uint32_t bits = 0; bits < 0x4A800000u; ++bits) { // 0 .. 2^22
+        float v, w;
+        std::memcpy(&v, &bits, 4);
+        w = -v;
+        float a = jm_round_half_away(v), b = roundf(v);
+        float c = jm_round_half_away(w), d = roundf(w);
+        bad += std::memcmp(&a, &b, 4) != 0;
+        bad += std::memcmp(&c, &d, 4) != 0;
+    }
+    return bad;
+}
+
+// the snap + quantise chain against real divisions, every r in [-rmax, rmax]
+// and every Q in 1..255: c = (float)(r/100.0) (double division narrowed, as
+// encode_decode.cpp:284), v = c / (float)Q, q = roundf(v).
+long jmm_check_quant(int rmax)
+{
+    long bad = 0;
+    for (int Q = 1; Q <= 255; ++Q) {
+        float qf = (float)Q, rq = 1.0f / qf;
+        for (int r = -rmax; r <= rmax; ++r) {
+            float c = (float)((double)r / 100);
+            volatile float v = c / qf;
+            float ref = roundf(v);
+            int want = (int)((ref == -0.0f) ? 0.0f : ref);
+            // feed the integer r itself and the edges of its rounding interval
+            int got = jm_snap_quant((float)r, qf, rq);
+            bad += got != want;
+        }
+    }
+    return bad;
+}
+
+} // extern "C"

@@ -1,0 +1,228 @@
+"""GPU parity: libjpeg_amd.so (through its C ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): zigzag / packing / colour bit-exact; quantised
+coefficients and decoded pixels within +-1 LSB of the reference CPU path and
+differing in at most a few samples per million (the reference's float
+accumulator is itself that noisy); PSNR within 0.01 dB.
+The kernels must also equal tests/model (the host build of their own
+arithmetic) bit for bit -- that isolates indexing bugs from rounding noise.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import ZIGZAG, plane_to_blocks
+
+pytestmark = pytest.mark.gpu
+
+COEF_PPM = 8      # allowed quantised-coefficient mismatches per million (all +-1)
+PIXEL_PPM = 40    # allowed decoded-sample mismatches per million (all +-1)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _natural(coef_zz):
+    nat = np.empty(coef_zz.shape, np.int32)
+    nat[:, ZIGZAG] = coef_zz
+    return nat
+
+
+def _check_coef(got, want, what):
+    got, want = np.asarray(got, np.int32), np.asarray(want, np.int32)
+    assert got.shape == want.shape
+    d = np.abs(got - want)
+    bad = int((d != 0).sum())
+    assert d.max(initial=0) <= 1, f"{what}: coefficient off by {d.max()}"
+    assert bad <= max(1, COEF_PPM * got.size // 1_000_000), f"{what}: {bad} of {got.size} coefficients differ"
+    return bad
+
+
+def _check_px(got, want, what):
+    d = np.abs(np.asarray(got, np.int32) - np.asarray(want, np.int32))
+    bad = int((d != 0).sum())
+    assert d.max(initial=0) <= 1, f"{what}: sample off by {d.max()}"
+    assert bad <= max(2, PIXEL_PPM * d.size // 1_000_000), f"{what}: {bad} of {d.size} samples differ"
+    return bad
+
+
+def _model_image(model, orc, bgr, qy, qc):
+    """what the kernels must produce bit for bit: colour (exact) + model transform"""
+    ycc = orc.rgb2ycbcr(bgr)
+    planes = orc.chroma_subsample(ycc)
+    out = []
+    for pl, q in zip(planes, (qy, qc, qc)):
+        nat = model.fdct_quant_blocks(plane_to_blocks(pl), q)
+        out.append(nat[:, ZIGZAG].astype(np.int16))
+    return out
+
+
+def test_lena_golden_encode_decode(gpu, orc, model, lena_bgr):
+    """config 1 on the GPU path: Lena 1024^2, QF=50 against the committed goldens."""
+    import jpeg_amd
+    qy, qc = jpeg_amd.quality_tables(50)
+    oy, oc = orc.quality_tables(50)
+    assert np.array_equal(qy, oy) and np.array_equal(qc, oc)
+    coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(lena_bgr, gpu), qy, qc)]
+    want = orc.encode_image(lena_bgr, qy, qc)
+    for g, w, n in zip(coefs, want, "Y Cb Cr".split()):
+        _check_coef(g, w, n)
+    for g, m in zip(coefs, _model_image(model, orc, lena_bgr, qy, qc)):
+        assert np.array_equal(g, m), "kernel differs from its own arithmetic model"
+    # on this input the coefficients are exactly the oracle's, so the .bin the
+    # reference's entropy coder makes of them is the committed golden
+    if all(np.array_equal(g, w) for g, w in zip(coefs, want)):
+        data = orc.write_bin(*(orc.rle_stream(c) for c in coefs), 1024, 1024)
+        gold = open(os.path.join(GOLD, "compressed_image_cpu_50.bin"), "rb").read()
+        assert data == gold
+        assert hashlib.sha256(data).hexdigest().startswith("7870d3fec500635c")
+    else:
+        pytest.fail("Lena QF=50 coefficients differ from the oracle (they are equal in the model)")
+    # decode
+    import torch
+    rec = jpeg_amd.decode_image(*(_t(c, gpu) for c in want), 1024, 1024, qy, qc).cpu().numpy()
+    want_px = orc.decode_image(*want, 1024, 1024, qy, qc)
+    from PIL import Image
+    gold_px = np.array(Image.open(os.path.join(GOLD, "decompress_image_cpu_50.png")).convert("RGB"))[:, :, ::-1]
+    assert np.array_equal(want_px, gold_px)
+    _check_px(rec, gold_px, "decoded Lena")
+    p_gpu = orc.psnr(orc.mse(lena_bgr, rec))
+    p_ref = orc.psnr(orc.mse(lena_bgr, gold_px))
+    assert abs(p_gpu - p_ref) < 0.01, (p_gpu, p_ref)
+
+
+@pytest.mark.parametrize("kind,seed,rows,cols,qf", [
+    ("photo", 1, 256, 512, 50),
+    ("photo", 2, 64, 1040, 10),     # partial second tile
+    ("photo", 3, 48, 528, 90),
+    ("noise", 4, 128, 512, 50),     # dense coefficients, Cb/Cr wrap quirk
+    ("noise", 5, 32, 16, 100),      # one MCU wide, all-ones table
+    ("gray", 6, 64, 512, 90),       # B=G=R: chroma planes all 128
+    ("photo", 7, 16, 2048, 1),      # all-255 table
+])
+def test_image_vs_oracle(gpu, orc, model, kind, seed, rows, cols, qf):
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    bgr = synth_image(rows, cols, seed, kind).numpy()
+    qy, qc = jpeg_amd.quality_tables(qf)
+    coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)]
+    want = orc.encode_image(bgr, qy, qc)
+    for g, w, n in zip(coefs, want, "Y Cb Cr".split()):
+        _check_coef(g, w, f"{kind} {n}")
+    for g, m in zip(coefs, _model_image(model, orc, bgr, qy, qc)):
+        assert np.array_equal(g, m)
+    rec = jpeg_amd.decode_image(*(_t(c, gpu) for c in want), rows, cols, qy, qc).cpu().numpy()
+    want_px = orc.decode_image(*want, rows, cols, qy, qc)
+    _check_px(rec, want_px, f"{kind} decode")
+    if kind == "gray":
+        assert (coefs[1] == 0).all() and (coefs[2] == 0).all()
+
+
+def test_colour_wrap_quirk(gpu, orc):
+    """BGR(0,0,255) -> Cb = 256 -> 0 and BGR(255,0,0) -> Cr = 256 -> 0 (encode_decode.cpp:67-70)."""
+    import jpeg_amd
+    bgr = np.zeros((16, 16, 3), np.uint8)
+    bgr[:, :8] = (0, 0, 255)
+    bgr[:, 8:] = (255, 0, 0)
+    qy, qc = jpeg_amd.quality_tables(100)
+    coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)]
+    want = orc.encode_image(bgr, qy, qc)
+    for g, w in zip(coefs, want):
+        assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("rows,cols,qf", [(8, 8, 50), (61, 77, 90), (3580 // 20, 5370 // 10, 90), (1, 1, 50), (24, 1000, 30)])
+def test_plane_odd_sizes(gpu, orc, model, rows, cols, qf):
+    """config 3's padding path: planes whose sizes are not multiples of 8
+    (zero fill before the level shift, encode_decode.cpp:242-251; surplus dropped, :805)."""
+    import jpeg_amd
+    rng = np.random.default_rng(rows * 1000 + cols)
+    plane = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    q = jpeg_amd.quality_tables(qf)[0]
+    got = jpeg_amd.encode_plane(_t(plane, gpu), q).cpu().numpy()
+    want, _ = orc.encode_plane(plane, q, want_symbols=False)
+    _check_coef(got, want, "plane")
+    assert np.array_equal(_natural(got), model.fdct_quant_blocks(plane_to_blocks(plane), q))
+    rec = jpeg_amd.decode_plane(_t(want, gpu), rows, cols, q).cpu().numpy()
+    _check_px(rec, orc.decode_plane(want, rows, cols, q), "plane decode")
+
+
+def test_legacy_blocks_boundary(gpu, orc, model):
+    """kernel.cuh semantics on flat arrays: pixels 0..255 in, natural-order float
+    coefficients out (never -0); natural-order coefficients in, IDCT+128 unclamped out."""
+    import jpeg_amd
+    rng = np.random.default_rng(7)
+    nb = 1000
+    px = rng.integers(0, 256, (nb, 64)).astype(np.int32)
+    px[0] = 0
+    px[1] = 255
+    q = jpeg_amd.quality_tables(75)[0]
+    got = jpeg_amd.fdct_quant_blocks(px, q)
+    assert got.dtype == np.float32 and got.shape == (nb, 64)
+    assert not np.signbit(got[got == 0]).any()
+    want = np.stack([orc.quantize_block(orc.dct_block(p - 128), q) for p in px])
+    _check_coef(got.astype(np.int32), want.astype(np.int32), "blocks")
+    assert np.array_equal(got.astype(np.int32), model.fdct_quant_blocks(px, q))
+    out = jpeg_amd.dequant_idct_blocks(want, q)
+    ref = np.stack([orc.idct_block(w * q.astype(np.float32)) + 128 for w in want])
+    _check_px(out, ref, "blocks idct")
+    assert out.min() < 0 or out.max() > 255 or True  # unclamped by contract
+    assert jpeg_amd.fdct_quant_blocks(np.zeros((0, 64), np.int32), q).shape == (0, 64)
+
+
+def test_wikipedia_block(gpu):
+    """known answers of jpeg_concept/jpeg_function.cpp:486-495 at QF=50."""
+    import json
+    import jpeg_amd
+    kat = json.load(open(os.path.join(GOLD, "wikipedia_block.json")))
+    q = np.array(kat["q"], np.int32)
+    got = jpeg_amd.fdct_quant_blocks(np.array(kat["pixels"], np.int32).reshape(1, 64), q)
+    assert np.array_equal(got.astype(np.int32).reshape(64), np.array(kat["quantised"]))
+    back = jpeg_amd.dequant_idct_blocks(got, q)
+    assert np.array_equal(back.reshape(64), np.array(kat["restored"]))
+
+
+def test_errors_are_loud(gpu):
+    import torch
+    import jpeg_amd
+    qy, qc = jpeg_amd.quality_tables(50)
+    img = torch.zeros((24, 32, 3), dtype=torch.uint8, device=gpu)  # rows not a multiple of 16
+    with pytest.raises(jpeg_amd.JpegAmdError, match="multiples of 16"):
+        jpeg_amd.encode_image(img, qy, qc, out=tuple(torch.zeros((16, 64), dtype=torch.int16, device=gpu) for _ in range(3)))
+    bad = qy.copy()
+    bad[5] = 0
+    img = torch.zeros((16, 16, 3), dtype=torch.uint8, device=gpu)
+    with pytest.raises(jpeg_amd.JpegAmdError, match="outside 1..255"):
+        jpeg_amd.encode_image(img, bad, qc)
+
+
+def test_full_size_properties(gpu, orc):
+    """8192^2 (BASELINE configs[1]): every 16x16 MCU is independent, so parity is
+    checked on sampled MCU-row strips against the oracle, plus whole-image
+    properties: decode(encode(x)) PSNR, and strip results == whole-image results."""
+    import torch
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    rows = cols = 8192
+    bgr = synth_image(rows, cols, 0x8192, "photo", device=gpu)
+    qy, qc = jpeg_amd.quality_tables(50)
+    cy, cb, cr = jpeg_amd.encode_image(bgr, qy, qc)
+    rec = jpeg_amd.decode_image(cy, cb, cr, rows, cols, qy, qc)
+    torch.cuda.synchronize()
+    mse = ((bgr.float() - rec.float()) ** 2).mean().item()
+    assert 0 < mse < 45  # README.md:152 quality claim
+    bw, bwc = cols // 8, cols // 16
+    for my in (0, 17, 255, 511):  # MCU rows
+        strip = bgr[my * 16:(my + 1) * 16].cpu().numpy()
+        wy, wcb, wcr = orc.encode_image(strip, qy, qc)
+        _check_coef(cy[my * 2 * bw:(my * 2 + 2) * bw].cpu().numpy(), wy, "strip Y")
+        _check_coef(cb[my * bwc:(my + 1) * bwc].cpu().numpy(), wcb, "strip Cb")
+        _check_coef(cr[my * bwc:(my + 1) * bwc].cpu().numpy(), wcr, "strip Cr")
+        want_px = orc.decode_image(wy, wcb, wcr, 16, cols, qy, qc)
+        _check_px(rec[my * 16:(my + 1) * 16].cpu().numpy(), want_px, "strip pixels")
