@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode Mpixel/s of the fused MI355X path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one image already resident in HBM:
+one fused encode launch (BGR -> zigzag int16 coefficient planes) followed by one
+fused decode launch (coefficients -> BGR).  N = 1 runs BASELINE.json configs[1]
+(synthetic 8192x8192 RGB, QF=50).  N > 1 is the batch configuration: every rank
+owns whole images (no data-path collective), so scaling is weak
+and `value` is the aggregate over ranks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu]
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_PIXEL_ENC = 6.0  # 3 B BGR read + 1.5 coefficients x 2 B written
+BYTES_PER_PIXEL_DEC = 6.0  # 3 B coefficients read + 3 B BGR written
+
+
+def cpu_baseline(bgr_crop, qy, qc):
+    """The oracle (kind "port") timed on host cores, on a bounded crop of the same
+    workload: single thread = the reference's CPU path (encodeChannel /
+    decodeChannel arithmetic + colour stages)."""
+    import numpy as np
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    r, c = bgr_crop.shape[:2]
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    cy = np.empty(((r // 8) * (c // 8), 64), np.int16)
+    cb = np.empty(((r // 16) * (c // 16), 64), np.int16)
+    cr = np.empty_like(cb)
+    out = np.empty_like(bgr_crop)
+    qy = np.ascontiguousarray(qy, np.int32)
+    qc = np.ascontiguousarray(qc, np.int32)
+    res = {}
+    for name, flavour, threads in (("cpu_1t", 0, 1), ("omp_all", 1, min(16, lib.orc_max_threads()))):
+        t0 = time.perf_counter()
+        assert lib.orc_encode_image(p(bgr_crop), r, c, p(qy), p(qc), flavour, threads, p(cy), p(cb), p(cr), None) == 0
+        assert lib.orc_decode_image(p(cy), p(cb), p(cr), r, c, p(qy), p(qc), flavour, threads, p(out)) == 0
+        dt = time.perf_counter() - t0
+        res[name] = {"mpix_s": r * c / dt / 1e6, "threads": threads, "seconds": dt}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=8192, help="image is size x size")
+    ap.add_argument("--quality", type=int, default=50)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    jpeg_amd.init(local)
+    dev = torch.device("cuda", local)
+
+    rows = cols = args.size
+    qy, qc = jpeg_amd.quality_tables(args.quality)
+    # every rank owns its own image (seed differs per rank): batch sharding
+    bgr = synth_image(rows, cols, 0x8192 + rank, "photo", device=dev)
+    coefs = tuple(torch.empty((n, 64), dtype=torch.int16, device=dev)
+                  for n in ((rows // 8) * (cols // 8), (rows // 16) * (cols // 16), (rows // 16) * (cols // 16)))
+    rec = torch.empty_like(bgr)
+
+    def step():
+        jpeg_amd.encode_image(bgr, qy, qc, out=coefs)
+        jpeg_amd.decode_image(*coefs, rows, cols, qy, qc, out=rec)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel launch durations, HIP events on the launching stream
+    enc_ms, dec_ms = jpeg_amd.time_image(bgr, coefs, rec, qy, qc, max(10, args.steps))
+    npix = rows * cols
+    enc_gbs = BYTES_PER_PIXEL_ENC * npix / (enc_ms * 1e-3) / 1e9
+    dec_gbs = BYTES_PER_PIXEL_DEC * npix / (dec_ms * 1e-3) / 1e9
+
+    # cheap whole-image sanity on what was just timed (not the parity test)
+    mse = float(((bgr.float() - rec.float()) ** 2).mean().item())
+
+    if rank == 0:
+        dominant = "encode_image_kernel" if enc_ms >= dec_ms else "decode_image_kernel"
+        ach = enc_gbs if enc_ms >= dec_ms else dec_gbs
+        line = {
+            "metric": "encode+decode Mpixel/s at 8192^2 QF=50",
+            "value": world * npix * args.steps / dt / 1e6,
+            "unit": "Mpixel/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {rows}x{cols} RGB QF={args.quality} encode+decode, "
+                                   f"one image per GPU resident in HBM (BASELINE configs[1])",
+                       "images_per_step_per_gpu": 1, "parallelism": f"batch x{world} (whole images per rank)"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_ENC * npix,
+                         "encode_ms": enc_ms, "decode_ms": dec_ms,
+                         "encode_GBs": enc_gbs, "decode_GBs": dec_gbs,
+                         "enc_plus_dec_frac_of_peak": (BYTES_PER_PIXEL_ENC + BYTES_PER_PIXEL_DEC) * npix
+                                                      / ((enc_ms + dec_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roundtrip_mse": mse,
+        }
+        if not args.no_cpu:
+            crop = 2048 if rows >= 2048 else rows
+            host = bgr[:crop, :crop].contiguous().cpu().numpy()
+            base = cpu_baseline(host, qy, qc)
+            line["cpu_baseline"] = {
+                "value": base["cpu_1t"]["mpix_s"], "unit": "Mpixel/s", "cores": 1, "kind": "port",
+                "sample": f"top-left {crop}x{crop} crop of the same image, encode+decode, oracle single thread "
+                          f"({base['cpu_1t']['seconds']:.1f} s)",
+                "omp_flavour": {"value": base["omp_all"]["mpix_s"], "cores": base["omp_all"]["threads"],
+                                "note": "separable OMP-path arithmetic (encode_decode.cpp:849-1035) on all box cores"},
+            }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,8 @@ from oracle_lib import ZIGZAG, plane_to_blocks
 pytestmark = pytest.mark.gpu
 
 COEF_PPM = 8      # allowed quantised-coefficient mismatches per million (all +-1)
-PIXEL_PPM = 40    # allowed decoded-sample mismatches per million (all +-1)
+PIXEL_PPM = 40    # allowed decoded plane-sample mismatches per million (all +-1)
+BGR_PPM = 480     # B,G,R output: one chroma sample feeds 2x2 pixels x 3 channels = 12 output samples
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -44,11 +45,15 @@ def _check_coef(got, want, what):
     return bad
 
 
-def _check_px(got, want, what):
+def _check_px(got, want, what, lsb=1):
+    """lsb=1 for plane samples (Y, Cb, Cr).  For B,G,R output use lsb=2: one LSB
+    of Cb or Cr is scaled by up to 1.772 in YCbCr2RGB (encode_decode.cpp:81-83),
+    so a +-1 chroma sample can move an output channel by 2."""
     d = np.abs(np.asarray(got, np.int32) - np.asarray(want, np.int32))
     bad = int((d != 0).sum())
-    assert d.max(initial=0) <= 1, f"{what}: sample off by {d.max()}"
-    assert bad <= max(2, PIXEL_PPM * d.size // 1_000_000), f"{what}: {bad} of {d.size} samples differ"
+    assert d.max(initial=0) <= lsb, f"{what}: sample off by {d.max()}"
+    ppm = PIXEL_PPM if lsb == 1 else BGR_PPM
+    assert bad <= max(12, ppm * d.size // 1_000_000), f"{what}: {bad} of {d.size} samples differ"
     return bad
 
 
@@ -91,7 +96,7 @@ def test_lena_golden_encode_decode(gpu, orc, model, lena_bgr):
     from PIL import Image
     gold_px = np.array(Image.open(os.path.join(GOLD, "decompress_image_cpu_50.png")).convert("RGB"))[:, :, ::-1]
     assert np.array_equal(want_px, gold_px)
-    _check_px(rec, gold_px, "decoded Lena")
+    _check_px(rec, gold_px, "decoded Lena", lsb=2)
     p_gpu = orc.psnr(orc.mse(lena_bgr, rec))
     p_ref = orc.psnr(orc.mse(lena_bgr, gold_px))
     assert abs(p_gpu - p_ref) < 0.01, (p_gpu, p_ref)
@@ -119,7 +124,7 @@ def test_image_vs_oracle(gpu, orc, model, kind, seed, rows, cols, qf):
         assert np.array_equal(g, m)
     rec = jpeg_amd.decode_image(*(_t(c, gpu) for c in want), rows, cols, qy, qc).cpu().numpy()
     want_px = orc.decode_image(*want, rows, cols, qy, qc)
-    _check_px(rec, want_px, f"{kind} decode")
+    _check_px(rec, want_px, f"{kind} decode", lsb=2)
     if kind == "gray":
         assert (coefs[1] == 0).all() and (coefs[2] == 0).all()
 
@@ -225,4 +230,4 @@ def test_full_size_properties(gpu, orc):
         _check_coef(cb[my * bwc:(my + 1) * bwc].cpu().numpy(), wcb, "strip Cb")
         _check_coef(cr[my * bwc:(my + 1) * bwc].cpu().numpy(), wcr, "strip Cr")
         want_px = orc.decode_image(wy, wcb, wcr, 16, cols, qy, qc)
-        _check_px(rec[my * 16:(my + 1) * 16].cpu().numpy(), want_px, "strip pixels")
+        _check_px(rec[my * 16:(my + 1) * 16].cpu().numpy(), want_px, "strip pixels", lsb=2)
