@@ -1,0 +1,45 @@
+"""The drop-in boundary: libjpeg_amd.so loads without a GPU, exports every
+symbol include/jpeg_amd.h declares, and refuses to compute without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "jpeg_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jpegamd_\w+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    import jpeg_amd
+    lib = ctypes.CDLL(jpeg_amd.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/jpeg_amd.h but not exported"
+    # and the Python binding table covers the same set
+    from jpeg_amd import _lib
+    assert sorted(list(_lib.SIGNATURES) + ["jpegamd_last_error"]) == names
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import jpeg_amd
+    with pytest.raises(jpeg_amd.JpegAmdError, match="no CPU fallback"):
+        jpeg_amd.init(0)
+
+
+def test_product_never_touches_the_oracle():
+    """nothing under jpeg_amd/ (sources or Python) may reference oracle/ or tests/"""
+    for base, _, files in os.walk(os.path.join(ROOT, "jpeg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "liboracle" not in text and "orc_" not in text and "libjmmodel" not in text, f

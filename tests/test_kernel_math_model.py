@@ -1,0 +1,59 @@
+"""The kernels' arithmetic (jpeg_amd/csrc/jpeg_math.h, built for the host in
+tests/model) against the oracle -- exhaustively where the domain is finite.
+CPU only; the GPU tests then require kernel == model bit for bit."""
+import numpy as np
+import pytest
+
+from oracle_lib import ZIGZAG, plane_to_blocks
+
+
+def test_arithmetic_shortcuts_are_exact(model):
+    assert model.lib.jmm_check_const_div() == 0      # the two divisions by constants
+    assert model.lib.jmm_check_quant(1 << 17) == 0   # snap + quantise vs real float divisions, all (r, Q)
+
+
+@pytest.mark.slow
+def test_round_half_away_every_float(model):
+    assert model.lib.jmm_check_round() == 0          # every float below 2^22, both signs
+
+
+def _all_triples():
+    a = np.arange(1 << 24, dtype=np.uint32)
+    return np.stack([(a >> 16) & 255, (a >> 8) & 255, a & 255], -1).astype(np.uint8).reshape(1, -1, 3)
+
+
+def test_forward_colour_all_triples(model, orc):
+    t = _all_triples()
+    assert np.array_equal(model.fwd_colour(t), orc.rgb2ycbcr(t))
+
+
+def test_inverse_colour_all_triples(model, orc):
+    t = _all_triples()
+    assert np.array_equal(model.inv_colour(t), orc.ycbcr2rgb(t))
+
+
+@pytest.mark.parametrize("qf", [10, 50, 90, 100])
+def test_transform_mismatch_rate_on_lena(model, orc, lena_bgr, qf):
+    """+-1 and only a few per million: the bar the GPU tests then inherit."""
+    qy, qc = orc.quality_tables(qf)
+    planes = orc.chroma_subsample(orc.rgb2ycbcr(lena_bgr))
+    nbad = ntot = pbad = ptot = 0
+    for pl, q in zip(planes, (qy, qc, qc)):
+        want, _ = orc.encode_plane(pl, q, want_symbols=False)
+        nat = np.empty(want.shape, np.int32)
+        nat[:, ZIGZAG] = want
+        got = model.fdct_quant_blocks(plane_to_blocks(pl), q)
+        d = np.abs(got - nat)
+        assert d.max() <= 1
+        nbad += int((d != 0).sum())
+        ntot += d.size
+        px = np.clip(model.dequant_idct_blocks(nat, q), 0, 255)
+        ref = plane_to_blocks(orc.decode_plane(want, pl.shape[0], pl.shape[1], q))
+        e = np.abs(px - ref)
+        assert e.max() <= 1
+        pbad += int((e != 0).sum())
+        ptot += e.size
+    assert nbad <= 8 * ntot // 1_000_000 + 1, (nbad, ntot)
+    assert pbad <= 40 * ptot // 1_000_000 + 1, (pbad, ptot)
+    if qf == 50:
+        assert nbad == 0  # hence a byte-identical .bin on the golden input
