@@ -140,7 +140,7 @@ __device__ __forceinline__ void stage_read_dequant(const uint8_t *stage, int lan
 
 // ------------------------------------------------------------- fused encoder
 // grid: one wave per 512x16 tile, 4 waves per workgroup.
-__global__ __launch_bounds__(256) void encode_image_kernel(
+__global__ __launch_bounds__(256, 3) void encode_image_kernel(
     const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
     int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
     int tiles_x, int n_tiles)
@@ -158,31 +158,50 @@ __global__ __launch_bounds__(256) void encode_image_kernel(
     const int x0 = tx * kWaveTileW;
     const int bw_y = cols >> 3, bw_c = cols >> 4;
 
+    // BGR rows stream through three register slots (two tasks of loads in
+    // flight behind the one being converted).  Task T = 8*it + t covers
+    // 2 rows x 4 pixels per lane: row pair rp = t>>1, pixel group g = lane + 64*(t&1).
+    auto task_ptr = [&](int T) -> const uint8_t * {
+        const int t = T & 7;
+        const int row = ty * 16 + (T >> 3) * 8 + 2 * (t >> 1);
+        const int x = x0 + 4 * (lane + 64 * (t & 1));
+        return x < cols ? bgr + (size_t)row * stride + (size_t)x * 3 : nullptr;
+    };
+    auto task_load = [&](int T, U3 &a, U3 &b) {
+        const uint8_t *p = task_ptr(T);
+        if (p) {
+            a = *reinterpret_cast<const U3 *>(p);
+            b = *reinterpret_cast<const U3 *>(p + stride);
+        }
+    };
+    U3 cur_a = {0, 0, 0}, cur_b = {0, 0, 0}, nxt_a = {0, 0, 0}, nxt_b = {0, 0, 0};
+    task_load(0, cur_a, cur_b);
+    task_load(1, nxt_a, nxt_b);
+
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
         if (it < 2) {
             // ---- colour + 4:2:0 for tile rows 8*it .. 8*it+7 -----------------
-            const int row_base = ty * 16 + it * 8;
-#pragma unroll
+#pragma unroll 1
             for (int t = 0; t < 8; ++t) {
+                const int T = it * 8 + t;
+                U3 far_a = {0, 0, 0}, far_b = {0, 0, 0};
+                if (T + 2 < 16)
+                    task_load(T + 2, far_a, far_b);
                 const int rp = t >> 1;
                 const int g = lane + 64 * (t & 1);
-                const int x = x0 + 4 * g;
-                if (x < cols) {
-                    const uint8_t *p0 = bgr + (size_t)(row_base + 2 * rp) * stride + (size_t)x * 3;
-                    U3 a = *reinterpret_cast<const U3 *>(p0);
-                    U3 b = *reinterpret_cast<const U3 *>(p0 + stride);
+                if (x0 + 4 * g < cols) {
                     uint32_t ya = 0, yb = 0;
                     int cbs[2] = {0, 0}, crs[2] = {0, 0};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         int y, cb, cr;
-                        jm_fwd_colour(u3_byte(a, 3 * j), u3_byte(a, 3 * j + 1), u3_byte(a, 3 * j + 2),
+                        jm_fwd_colour(u3_byte(cur_a, 3 * j), u3_byte(cur_a, 3 * j + 1), u3_byte(cur_a, 3 * j + 2),
                                       y, cb, cr);
                         ya |= (uint32_t)y << (8 * j);
                         cbs[j >> 1] += cb;
                         crs[j >> 1] += cr;
-                        jm_fwd_colour(u3_byte(b, 3 * j), u3_byte(b, 3 * j + 1), u3_byte(b, 3 * j + 2),
+                        jm_fwd_colour(u3_byte(cur_b, 3 * j), u3_byte(cur_b, 3 * j + 1), u3_byte(cur_b, 3 * j + 2),
                                       y, cb, cr);
                         yb |= (uint32_t)y << (8 * j);
                         cbs[j >> 1] += cb;
@@ -197,6 +216,8 @@ __global__ __launch_bounds__(256) void encode_image_kernel(
                     *reinterpret_cast<uint16_t *>(cbuf + crow * 256 + 2 * g) = cbp;
                     *reinterpret_cast<uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g) = crp;
                 }
+                cur_a = nxt_a, cur_b = nxt_b;
+                nxt_a = far_a, nxt_b = far_b;
             }
         }
         wave_lds_fence();
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(256) void encode_image_kernel(
 }
 
 // ------------------------------------------------------------- fused decoder
-__global__ __launch_bounds__(256) void decode_image_kernel(
+__global__ __launch_bounds__(256, 3) void decode_image_kernel(
     const int16_t *__restrict__ coef_y, const int16_t *__restrict__ coef_cb,
     const int16_t *__restrict__ coef_cr, int rows, int cols, QuantPair qp,
     uint8_t *__restrict__ bgr, size_t stride, int tiles_x, int n_tiles)
@@ -322,7 +343,7 @@ __global__ __launch_bounds__(256) void decode_image_kernel(
         if (luma) {
             // ---- upsample + YCbCr2RGB for tile rows 8*(it-1) .. +7 ------------
             const int row_base = ty * 16 + (it - 1) * 8;
-#pragma unroll
+#pragma unroll 2
             for (int t = 0; t < 8; ++t) {
                 const int rp = t >> 1;
                 const int g = lane + 64 * (t & 1);
