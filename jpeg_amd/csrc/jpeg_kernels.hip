@@ -27,10 +27,7 @@
 namespace {
 
 // ------------------------------------------------------------------ constants
-struct QuantConsts {
-    float q[64];  // (float)Q, natural order
-    float rq[64]; // RN(1/Q)
-};
+typedef JmQuantTab QuantConsts; // inv100q (biased) and q, natural order (jpeg_math.h)
 struct QuantPair {
     QuantConsts t[2]; // [0] luma, [1] chroma
 };
@@ -69,9 +66,11 @@ __device__ __forceinline__ int u3_byte(const U3 &v, int idx)
 }
 
 // ------------------------------------------------------------ transform stage
-// v: 64 pixel values (row-major).  Returns quantised coefficients in v's place
-// as ints, natural order.
-__device__ __forceinline__ void block_fdct_quant(float (&v)[64], int (&qv)[64], const QuantConsts &qc)
+// v: 64 pixel values (row-major) on entry; on exit v[i] = MAGIC + quantised
+// coefficient i (natural order): the int16 value sits in the low 16 bits.
+// Straight-line code on purpose: with no branch in it the scheduler keeps the
+// whole transform near 80 VGPRs.
+__device__ __forceinline__ void block_fdct_quant(float (&v)[64], const QuantConsts &qc)
 {
 #pragma unroll
     for (int r = 0; r < 8; ++r)
@@ -81,13 +80,12 @@ __device__ __forceinline__ void block_fdct_quant(float (&v)[64], int (&qv)[64], 
     for (int c = 0; c < 8; ++c)
         jm_fdct8<100, false>(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
                              v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
-#pragma unroll
-    for (int i = 0; i < 64; ++i)
-        qv[i] = jm_snap_quant(v[i], qc.q[i], qc.rq[i]);
+    jm_quantise_block(v, qc);
 }
 
-// v: 64 dequantised coefficients (natural order) -> pixel values + 128 (unclamped)
-__device__ __forceinline__ void block_idct(float (&v)[64], int (&px)[64])
+// v: 64 dequantised coefficients (natural order) on entry; on exit v[i] = MAGIC +
+// 128 + pixel i (unclamped): the int16 value sits in the low 16 bits.
+__device__ __forceinline__ void block_idct(float (&v)[64])
 {
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -99,11 +97,11 @@ __device__ __forceinline__ void block_idct(float (&v)[64], int (&px)[64])
                  v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
 #pragma unroll
     for (int i = 0; i < 64; ++i)
-        px[i] = jm_round_pixel(v[i]);
+        v[i] = jm_pixel_magic(v[i]);
 }
 
 // quantised block -> 128 bytes in zigzag order at stage + lane*144
-__device__ __forceinline__ void stage_write_zigzag(const int (&qv)[64], uint8_t *stage, int lane)
+__device__ __forceinline__ void stage_write_zigzag(const float (&qv)[64], uint8_t *stage, int lane)
 {
     uint4 *dst = reinterpret_cast<uint4 *>(stage + lane * kStagePitch);
 #pragma unroll
@@ -112,7 +110,7 @@ __device__ __forceinline__ void stage_write_zigzag(const int (&qv)[64], uint8_t 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int i = (k * 4 + j) * 2;
-            w[j] = ((uint32_t)qv[kZZ[i]] & 0xFFFFu) | ((uint32_t)qv[kZZ[i + 1]] << 16);
+            w[j] = jm_pack_lo16(jm_bits(qv[kZZ[i]]), jm_bits(qv[kZZ[i + 1]]));
         }
         dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -191,30 +189,34 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                 const int rp = t >> 1;
                 const int g = lane + 64 * (t & 1);
                 if (x0 + 4 * g < cols) {
-                    uint32_t ya = 0, yb = 0;
-                    int cbs[2] = {0, 0}, crs[2] = {0, 0};
+                    float ya[4], yb[4], sum_b[2] = {0.f, 0.f}, sum_r[2] = {0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        int y, cb, cr;
-                        jm_fwd_colour(u3_byte(cur_a, 3 * j), u3_byte(cur_a, 3 * j + 1), u3_byte(cur_a, 3 * j + 2),
-                                      y, cb, cr);
-                        ya |= (uint32_t)y << (8 * j);
-                        cbs[j >> 1] += cb;
-                        crs[j >> 1] += cr;
-                        jm_fwd_colour(u3_byte(cur_b, 3 * j), u3_byte(cur_b, 3 * j + 1), u3_byte(cur_b, 3 * j + 2),
-                                      y, cb, cr);
-                        yb |= (uint32_t)y << (8 * j);
-                        cbs[j >> 1] += cb;
-                        crs[j >> 1] += cr;
+#pragma unroll
+                        for (int row = 0; row < 2; ++row) {
+                            const U3 &px = row ? cur_b : cur_a;
+                            float uy, cb, cr;
+                            uint32_t tie = 0;
+                            jm_fwd_colour_fast((float)u3_byte(px, 3 * j), (float)u3_byte(px, 3 * j + 1),
+                                               (float)u3_byte(px, 3 * j + 2), uy, cb, cr, tie);
+                            if (__builtin_expect((int32_t)tie < 0, 0)) // an exact x.5 somewhere: ask the doubles
+                                jm_fwd_colour_exact(u3_byte(px, 3 * j), u3_byte(px, 3 * j + 1),
+                                                    u3_byte(px, 3 * j + 2), uy, cb, cr);
+                            (row ? yb : ya)[j] = uy;
+                            sum_b[j >> 1] += cb;
+                            sum_r[j >> 1] += cr;
+                        }
                     }
+                    *reinterpret_cast<uint32_t *>(stage + (2 * rp) * 512 + 4 * g) =
+                        jm_pack_lo8x4(ya[0], ya[1], ya[2], ya[3]);
+                    *reinterpret_cast<uint32_t *>(stage + (2 * rp + 1) * 512 + 4 * g) =
+                        jm_pack_lo8x4(yb[0], yb[1], yb[2], yb[3]);
                     // chromaSubsampling: truncating mean of the quad (:139-149)
-                    uint16_t cbp = (uint16_t)((cbs[0] >> 2) | ((cbs[1] >> 2) << 8));
-                    uint16_t crp = (uint16_t)((crs[0] >> 2) | ((crs[1] >> 2) << 8));
-                    *reinterpret_cast<uint32_t *>(stage + (2 * rp) * 512 + 4 * g) = ya;
-                    *reinterpret_cast<uint32_t *>(stage + (2 * rp + 1) * 512 + 4 * g) = yb;
                     const int crow = it * 4 + rp;
-                    *reinterpret_cast<uint16_t *>(cbuf + crow * 256 + 2 * g) = cbp;
-                    *reinterpret_cast<uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g) = crp;
+                    *reinterpret_cast<uint16_t *>(cbuf + crow * 256 + 2 * g) = (uint16_t)jm_pack_lo8x4(
+                        jm_quad_mean_magic(sum_b[0]), jm_quad_mean_magic(sum_b[1]), 0.f, 0.f);
+                    *reinterpret_cast<uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g) = (uint16_t)jm_pack_lo8x4(
+                        jm_quad_mean_magic(sum_r[0]), jm_quad_mean_magic(sum_r[1]), 0.f, 0.f);
                 }
                 cur_a = nxt_a, cur_b = nxt_b;
                 nxt_a = far_a, nxt_b = far_b;
@@ -228,7 +230,6 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
         const int pitch = luma ? 512 : 256;
         const int bcol = luma ? tx * 64 + lane : tx * 32 + (lane & 31);
         const bool valid = bcol < (luma ? bw_y : bw_c);
-        int qv[64];
         if (valid) {
             float v[64];
 #pragma unroll
@@ -240,11 +241,13 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                     v[r * 8 + 4 + j] = (float)((d.y >> (8 * j)) & 0xFFu);
                 }
             }
-            block_fdct_quant(v, qv, qp.t[luma ? 0 : 1]);
+            block_fdct_quant(v, qp.t[luma ? 0 : 1]);
+            // The staging area aliases the Y rows.  LDS instructions of one wave
+            // retire in program order, so every lane's reads above are done before
+            // the writes below; the fence only pins the compiler's order.
+            wave_lds_fence();
+            stage_write_zigzag(v, stage, lane);
         }
-        wave_lds_fence(); // every lane has its pixels: the Y rows may be overwritten
-        if (valid)
-            stage_write_zigzag(qv, stage, lane);
         wave_lds_fence();
 
         // ---- coalesced store: 64 blocks x 128 B = 8 x (64 lanes x 16 B) ------
@@ -316,25 +319,18 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
         // ---- transform: lane = block ---------------------------------------
         const int bcol = luma ? tx * 64 + lane : tx * 32 + (lane & 31);
         const bool valid = bcol < (luma ? bw_y : bw_c);
-        int px[64];
         if (valid) {
             float v[64];
             stage_read_dequant(stage, lane, v, qp.t[luma ? 0 : 1]);
-            block_idct(v, px);
-        }
-        wave_lds_fence(); // staged coefficients consumed: Y rows may overwrite them
-        if (valid) {
+            block_idct(v);
+            wave_lds_fence(); // staged coefficients consumed (in-order LDS): Y rows may overwrite them
             uint8_t *dst = luma ? stage + lane * 8 : cbuf + (lane >> 5) * 2048 + (lane & 31) * 8;
             const int pitch = luma ? 512 : 256;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                uint32_t lo = 0, hi = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // std::clamp(block[i][j], 0, 255), encode_decode.cpp:808
-                    lo |= (uint32_t)jm_clamp255(px[r * 8 + j]) << (8 * j);
-                    hi |= (uint32_t)jm_clamp255(px[r * 8 + 4 + j]) << (8 * j);
-                }
+                // std::clamp(block[i][j], 0, 255), encode_decode.cpp:808
+                uint32_t lo = jm_pack4_u8(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]);
+                uint32_t hi = jm_pack4_u8(v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
                 *reinterpret_cast<uint2 *>(dst + r * pitch) = make_uint2(lo, hi);
             }
         }
@@ -405,7 +401,6 @@ __global__ __launch_bounds__(256) void encode_plane_kernel(
     uint8_t *stage = lds + wave * kStageBytes;
     const int bx = gx * 64 + lane;
     const bool valid = bx < bw;
-    int qv[64];
     if (valid) {
         float v[64];
         const int r0 = by * 8, c0 = bx * 8;
@@ -430,8 +425,8 @@ __global__ __launch_bounds__(256) void encode_plane_kernel(
                                        ? (float)plane[(size_t)(r0 + r) * stride + c0 + c]
                                        : 0.0f;
         }
-        block_fdct_quant(v, qv, qc);
-        stage_write_zigzag(qv, stage, lane);
+        block_fdct_quant(v, qc);
+        stage_write_zigzag(v, stage, lane);
     }
     wave_lds_fence();
 #pragma unroll
@@ -472,21 +467,16 @@ __global__ __launch_bounds__(256) void decode_plane_kernel(
     const int bx = gx * 64 + lane;
     if (bx < bw) {
         float v[64];
-        int px[64];
         stage_read_dequant(stage, lane, v, qc);
-        block_idct(v, px);
+        block_idct(v);
         const int r0 = by * 8, c0 = bx * 8;
         const bool interior = (r0 + 8 <= rows) && (c0 + 8 <= cols) && ((stride & 7) == 0) &&
                               ((reinterpret_cast<uintptr_t>(plane) & 7) == 0);
         if (interior) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                uint32_t lo = 0, hi = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    lo |= (uint32_t)jm_clamp255(px[r * 8 + j]) << (8 * j);
-                    hi |= (uint32_t)jm_clamp255(px[r * 8 + 4 + j]) << (8 * j);
-                }
+                uint32_t lo = jm_pack4_u8(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]);
+                uint32_t hi = jm_pack4_u8(v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
                 *reinterpret_cast<uint2 *>(plane + (size_t)(r0 + r) * stride + c0) = make_uint2(lo, hi);
             }
         } else {
@@ -495,7 +485,7 @@ __global__ __launch_bounds__(256) void decode_plane_kernel(
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
                     if (r0 + r < rows && c0 + c < cols) // encode_decode.cpp:805
-                        plane[(size_t)(r0 + r) * stride + c0 + c] = (uint8_t)jm_clamp255(px[r * 8 + c]);
+                        plane[(size_t)(r0 + r) * stride + c0 + c] = (uint8_t)jm_clamp255(jm_magic_to_int(v[r * 8 + c]));
         }
     }
 }
@@ -510,17 +500,17 @@ __global__ __launch_bounds__(256) void fdct_quant_blocks_kernel(
         return;
     const int4 *src = reinterpret_cast<const int4 *>(blocks + b * 64);
     float v[64];
-    int qv[64];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         int4 d = src[k];
         v[4 * k] = (float)d.x, v[4 * k + 1] = (float)d.y, v[4 * k + 2] = (float)d.z, v[4 * k + 3] = (float)d.w;
     }
-    block_fdct_quant(v, qv, qc);
+    block_fdct_quant(v, qc);
     float4 *dst = reinterpret_cast<float4 *>(out + b * 64);
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-        dst[k] = make_float4((float)qv[4 * k], (float)qv[4 * k + 1], (float)qv[4 * k + 2], (float)qv[4 * k + 3]);
+    for (int k = 0; k < 16; ++k) // MAGIC + q -> q (exact; +0 for 0, never -0: kernel.cu:86)
+        dst[k] = make_float4(v[4 * k] - JM_MAGIC, v[4 * k + 1] - JM_MAGIC, v[4 * k + 2] - JM_MAGIC,
+                             v[4 * k + 3] - JM_MAGIC);
 }
 
 __global__ __launch_bounds__(256) void dequant_idct_blocks_kernel(
@@ -531,18 +521,18 @@ __global__ __launch_bounds__(256) void dequant_idct_blocks_kernel(
         return;
     const float4 *src = reinterpret_cast<const float4 *>(coef + b * 64);
     float v[64];
-    int px[64];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         float4 d = src[k];
         v[4 * k] = d.x * qc.q[4 * k], v[4 * k + 1] = d.y * qc.q[4 * k + 1];
         v[4 * k + 2] = d.z * qc.q[4 * k + 2], v[4 * k + 3] = d.w * qc.q[4 * k + 3];
     }
-    block_idct(v, px);
+    block_idct(v);
     int4 *dst = reinterpret_cast<int4 *>(out + b * 64);
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-        dst[k] = make_int4(px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]);
+    for (int k = 0; k < 16; ++k) // unclamped (the caller clamps, encode_decode.cpp:808)
+        dst[k] = make_int4(jm_magic_to_int(v[4 * k]), jm_magic_to_int(v[4 * k + 1]),
+                           jm_magic_to_int(v[4 * k + 2]), jm_magic_to_int(v[4 * k + 3]));
 }
 
 // ------------------------------------------------------------------ host side
@@ -571,9 +561,8 @@ int make_consts(const int32_t q[64], QuantConsts &c, const char *what)
     for (int i = 0; i < 64; ++i) {
         if (q[i] < 1 || q[i] > 255)
             return fail("%s: quantisation entry %d = %d outside 1..255", what, i, q[i]);
-        c.q[i] = (float)q[i];
-        c.rq[i] = 1.0f / (float)q[i];
     }
+    jm_make_quant_tab(q, c);
     return 0;
 }
 

@@ -271,3 +271,160 @@ JM_HD int jm_round_pixel(float x)
     float y = x - jm_copysign(1.0e-5f, x);
     return (int)jm_rint(y) + 128;
 }
+
+// ===========================================================================
+// Block-level fast paths.  gfx950 issues v_fma/v_mul/v_add/v_sub (f32),
+// v_add/v_sub (int), and/or/xor and right shifts at full rate, and nearly
+// everything else (conversions, trunc/rndne, bfi, min/max/med3, 24-bit mads,
+// compares, perm) at about 0.6x that rate (tools/valu_ubench2.hip), so the
+// per-sample chains below are built from the first group: rounding is done by
+// adding and subtracting 1.5*2^23 ("magic"), which leaves the nearest integer
+// (ties to even) in the low mantissa bits of a float.
+// ===========================================================================
+#define JM_MAGIC 12582912.0f /* 1.5 * 2^23: ulp is 1 for values in [2^23, 2^24) */
+
+JM_HD uint32_t jm_bits(float f)
+{
+    return __builtin_bit_cast(uint32_t, f);
+}
+
+// low 16 bits of a, low 16 bits of b -> one dword (a in the low half)
+JM_HD uint32_t jm_pack_lo16(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(b, a, 0x05040100u);
+#else
+    return (a & 0xFFFFu) | (b << 16);
+#endif
+}
+
+// Quantiser constants for one table, natural order.
+struct JmQuantTab {
+    float inv100q[64]; // RN((1 + 2^-21) / (100 Q)): see jm_quantise_block
+    float q[64];       // Q (dequantisation)
+};
+
+JM_HD void jm_make_quant_tab(const int32_t q[64], JmQuantTab &t)
+{
+    for (int i = 0; i < 64; ++i) {
+        t.q[i] = (float)q[i];
+        t.inv100q[i] = (float)((1.0 + 0x1p-21) / (100.0 * (double)q[i]));
+    }
+}
+
+// x[i] = 100 * coefficient (natural order) on entry; on exit x[i] = MAGIC + q_i,
+// i.e. a float whose low 16 bits are the quantised coefficient as int16.
+//
+//   r = nearest integer of x: the reference's round(.. * 100) (:284).  Ties to
+//       even instead of away from zero only matters when the float x is exactly
+//       k + 0.5, which the reference's own accumulation noise makes immaterial.
+//   q = the reference's roundf((float)(r / 100) / Q) (:284, :306).  r/(100 Q) is
+//       a rational that is either an exact tie j + 0.5 or at least 1/(100 Q) away
+//       from one -- a relative distance of at least 1/|r| > 3.8e-6 for
+//       |r| < 2^18, far beyond float error -- so away from ties the reference's
+//       two float divisions cannot change the nearest integer.  AT an exact tie
+//       r = 50 Q (2j+1): r/100 = Q (2j+1) / 2 has at most 21 significant bits, so
+//       both divisions are exact, the quotient is exactly j + 0.5 and roundf takes
+//       it away from zero.  Hence q = round-half-away(r / (100 Q)) as a rational,
+//       which one fma delivers: the multiplier carries a 2^-21 relative push away
+//       from zero (more than the float error, less than the 3.8e-6 gap), and the
+//       magic add rounds to nearest.  tests/model checks every (r, Q) pair against
+//       real float divisions.
+JM_HD void jm_quantise_block(float (&x)[64], const JmQuantTab &t)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 64; ++i) {
+        float r = (x[i] + JM_MAGIC) - JM_MAGIC;
+        x[i] = jm_fma(r, t.inv100q[i], JM_MAGIC);
+    }
+}
+
+// IDCT output x = 0.25*sum (:591) -> float whose low 16 bits hold
+// round(x) + 128 as int16, with exact x.5 ties resolved toward zero like the
+// reference: x is first shrunk by 1.5e-7 of itself (a few
+// ulps: more than this kernel's own rounding error at a DC-only tie), then the
+// magic add rounds to nearest.
+JM_HD float jm_pixel_magic(float x)
+{
+    float z = jm_fma(x, -1.5e-7f, x);
+    return z + (JM_MAGIC + 128.0f);
+}
+
+JM_HD int jm_magic_to_int(float u)
+{
+    return (int)(int16_t)(jm_bits(u) & 0xFFFFu);
+}
+
+// four jm_pixel_magic values -> four bytes saturated to 0..255 (std::clamp, :808)
+JM_HD uint32_t jm_pack4_u8(float a, float b, float c, float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t ab = __builtin_amdgcn_perm(jm_bits(b), jm_bits(a), 0x05040100u);
+    uint32_t cd = __builtin_amdgcn_perm(jm_bits(d), jm_bits(c), 0x05040100u);
+    uint32_t sab, scd;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(sab) : "v"(ab));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(scd) : "v"(cd));
+    return __builtin_amdgcn_perm(scd, sab, 0x05040100u);
+#else
+    return (uint32_t)jm_clamp255(jm_magic_to_int(a)) | ((uint32_t)jm_clamp255(jm_magic_to_int(b)) << 8) |
+           ((uint32_t)jm_clamp255(jm_magic_to_int(c)) << 16) | ((uint32_t)jm_clamp255(jm_magic_to_int(d)) << 24);
+#endif
+}
+
+// ---------------------------------------------------------------- colour, fast
+// Forward: the same decision as jm_fwd_colour (exact rational rounding, with
+// exact x.5 ties handed to the reference's double sequence), but the common
+// case runs on float fma/add only.  Y comes from a direct float chain (error
+// < 1e-4, ties are 1e-3 apart); Cb and Cr from exact integer-valued float
+// numerators (< 2^24) times 1e-4 (error < 2e-5, ties 1e-4 apart).  A value is a
+// tie candidate when its distance to the nearest integer exceeds the threshold;
+// `tie` collects the sign bits of (threshold - distance).
+JM_HD void jm_fwd_colour_fast(float p0, float p1, float p2, float &uy, float &cb, float &cr, uint32_t &tie)
+{
+    float sy = jm_fma(p2, 0.114f, jm_fma(p1, 0.587f, p0 * 0.299f));
+    uy = sy + JM_MAGIC;
+    float ry = sy - (uy - JM_MAGIC);
+    float nb = jm_fma(p2, 5000.0f, jm_fma(p1, -3313.0f, jm_fma(p0, -1687.0f, 1280000.0f)));
+    float sb = nb * 1.0e-4f;
+    float ub = sb + JM_MAGIC;
+    cb = ub - JM_MAGIC;
+    float rb = sb - cb;
+    float nr = jm_fma(p2, -813.0f, jm_fma(p1, -4187.0f, jm_fma(p0, 5000.0f, 1280000.0f)));
+    float sr = nr * 1.0e-4f;
+    float ur = sr + JM_MAGIC;
+    cr = ur - JM_MAGIC;
+    float rr = sr - cr;
+    tie |= jm_bits(0.4995f - __builtin_fabsf(ry)) | jm_bits(0.49995f - __builtin_fabsf(rb)) |
+           jm_bits(0.49995f - __builtin_fabsf(rr));
+}
+
+// the exact answer for one pixel, in the fast path's output form
+JM_HD void jm_fwd_colour_exact(int p0, int p1, int p2, float &uy, float &cb, float &cr)
+{
+    int y, b, r;
+    jm_fwd_colour(p0, p1, p2, y, b, r);
+    uy = (float)y + JM_MAGIC;
+    cb = (float)b;
+    cr = (float)r;
+}
+
+// truncating mean of four chroma values (chromaSubsampling, :139-149) as MAGIC + mean
+JM_HD float jm_quad_mean_magic(float sum)
+{
+    return jm_fma(sum, 0.25f, -0.375f) + JM_MAGIC; // sum/4 is a multiple of 0.25: -0.375 makes nearest == floor
+}
+
+// low bytes of four magic floats -> one dword (a in byte 0)
+JM_HD uint32_t jm_pack_lo8x4(float a, float b, float c, float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t ab = __builtin_amdgcn_perm(jm_bits(b), jm_bits(a), 0x0C0C0400u);
+    uint32_t cd = __builtin_amdgcn_perm(jm_bits(d), jm_bits(c), 0x0C0C0400u);
+    return __builtin_amdgcn_perm(cd, ab, 0x05040100u);
+#else
+    return (jm_bits(a) & 0xFFu) | ((jm_bits(b) & 0xFFu) << 8) | ((jm_bits(c) & 0xFFu) << 16) |
+           ((jm_bits(d) & 0xFFu) << 24);
+#endif
+}

@@ -30,6 +30,25 @@ void jmm_fwd_colour(const uint8_t *src, size_t n, uint8_t *dst)
     }
 }
 
+// the kernels' fast forward path: float chains, tie candidates redone exactly
+void jmm_fwd_colour_fast(const uint8_t *src, size_t n, uint8_t *dst, long *n_candidates)
+{
+    long cand = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float uy, cb, cr;
+        uint32_t tie = 0;
+        jm_fwd_colour_fast((float)src[3 * i], (float)src[3 * i + 1], (float)src[3 * i + 2], uy, cb, cr, tie);
+        if ((int32_t)tie < 0) {
+            ++cand;
+            jm_fwd_colour_exact(src[3 * i], src[3 * i + 1], src[3 * i + 2], uy, cb, cr);
+        }
+        dst[3 * i] = (uint8_t)(jm_bits(uy) & 0xFFu);
+        dst[3 * i + 1] = (uint8_t)(int)cb;
+        dst[3 * i + 2] = (uint8_t)(int)cr;
+    }
+    *n_candidates = cand;
+}
+
 void jmm_inv_colour(const uint8_t *src, size_t n, uint8_t *dst)
 {
     for (size_t i = 0; i < n; ++i) {
@@ -46,11 +65,8 @@ void jmm_inv_colour(const uint8_t *src, size_t n, uint8_t *dst)
 // coefficients, natural order, exactly as the kernels' block stage does.
 void jmm_fdct_quant_blocks(const int32_t *px, size_t nb, const int32_t *q, int32_t *out)
 {
-    float qf[64], rq[64];
-    for (int i = 0; i < 64; ++i) {
-        qf[i] = (float)q[i];
-        rq[i] = 1.0f / qf[i];
-    }
+    JmQuantTab tab;
+    jm_make_quant_tab(q, tab);
     for (size_t b = 0; b < nb; ++b) {
         float v[64];
         for (int i = 0; i < 64; ++i)
@@ -61,8 +77,9 @@ void jmm_fdct_quant_blocks(const int32_t *px, size_t nb, const int32_t *q, int32
         for (int c = 0; c < 8; ++c) // columns, scaled by 100
             jm_fdct8<100, false>(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
                                  v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
+        jm_quantise_block(v, tab);
         for (int i = 0; i < 64; ++i)
-            out[b * 64 + i] = jm_snap_quant(v[i], qf[i], rq[i]);
+            out[b * 64 + i] = jm_magic_to_int(v[i]);
     }
 }
 
@@ -80,11 +97,20 @@ void jmm_dequant_idct_blocks(const int32_t *coef, size_t nb, const int32_t *q, i
             jm_idct8(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3],
                      v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
         for (int i = 0; i < 64; ++i)
-            out[b * 64 + i] = jm_round_pixel(v[i]);
+            out[b * 64 + i] = jm_magic_to_int(jm_pixel_magic(v[i]));
     }
 }
 
 const uint8_t *jmm_zigzag(void) { return kZigzag; }
+
+// every possible quad sum 0..1020 through the kernels' truncating-mean helper
+long jmm_check_quad_mean(void)
+{
+    long bad = 0;
+    for (int s = 0; s <= 1020; ++s)
+        bad += (int)(jm_bits(jm_quad_mean_magic((float)s)) & 0xFFu) != s / 4;
+    return bad;
+}
 
 // ---- exhaustive self-checks of the arithmetic shortcuts; return #failures --
 
@@ -123,6 +149,11 @@ long jmm_check_quant(int rmax)
     long bad = 0;
     for (int Q = 1; Q <= 255; ++Q) {
         float qf = (float)Q, rq = 1.0f / qf;
+        int32_t qq[64];
+        for (int i = 0; i < 64; ++i)
+            qq[i] = Q;
+        JmQuantTab tab;
+        jm_make_quant_tab(qq, tab);
         for (int r = -rmax; r <= rmax; ++r) {
             float c = (float)((double)r / 100);
             volatile float v = c / qf;
@@ -131,6 +162,9 @@ long jmm_check_quant(int rmax)
             // feed the integer r itself and the edges of its rounding interval
             int got = jm_snap_quant((float)r, qf, rq);
             bad += got != want;
+            // the kernels' quantiser: one fma with the biased multiplier
+            float u = fmaf((float)r, tab.inv100q[0], JM_MAGIC);
+            bad += jm_magic_to_int(u) != want;
         }
     }
     return bad;

@@ -265,6 +265,13 @@ class KernelMathModel:
         self.lib.jmm_fwd_colour(_p(img), C.c_size_t(img.size // 3), _p(out))
         return out
 
+    def fwd_colour_fast(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.empty_like(img)
+        cand = C.c_long(0)
+        self.lib.jmm_fwd_colour_fast(_p(img), C.c_size_t(img.size // 3), _p(out), C.byref(cand))
+        return out, cand.value
+
     def inv_colour(self, img):
         img = np.ascontiguousarray(img, np.uint8)
         out = np.empty_like(img)

@@ -9,7 +9,8 @@ from oracle_lib import ZIGZAG, plane_to_blocks
 
 def test_arithmetic_shortcuts_are_exact(model):
     assert model.lib.jmm_check_const_div() == 0      # the two divisions by constants
-    assert model.lib.jmm_check_quant(1 << 17) == 0   # snap + quantise vs real float divisions, all (r, Q)
+    assert model.lib.jmm_check_quad_mean() == 0      # truncating 2x2 chroma mean via magic rounding
+    assert model.lib.jmm_check_quant((1 << 18) - 1) == 0   # snap + quantise vs real float divisions, all (r, Q)
 
 
 @pytest.mark.slow
@@ -25,6 +26,14 @@ def _all_triples():
 def test_forward_colour_all_triples(model, orc):
     t = _all_triples()
     assert np.array_equal(model.fwd_colour(t), orc.rgb2ycbcr(t))
+
+
+def test_forward_colour_fast_path_all_triples(model, orc):
+    """the float chain the kernels run, with tie candidates redone exactly"""
+    t = _all_triples()
+    got, candidates = model.fwd_colour_fast(t)
+    assert np.array_equal(got, orc.rgb2ycbcr(t))
+    assert candidates < t.size // 3 // 150  # ~0.5 % of all triples are exact ties
 
 
 def test_inverse_colour_all_triples(model, orc):
