@@ -196,12 +196,12 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                         for (int row = 0; row < 2; ++row) {
                             const U3 &px = row ? cur_b : cur_a;
                             float uy, cb, cr;
-                            uint32_t tie = 0;
-                            jm_fwd_colour_fast((float)u3_byte(px, 3 * j), (float)u3_byte(px, 3 * j + 1),
-                                               (float)u3_byte(px, 3 * j + 2), uy, cb, cr, tie);
-                            if (__builtin_expect((int32_t)tie < 0, 0)) // an exact x.5 somewhere: ask the doubles
-                                jm_fwd_colour_exact(u3_byte(px, 3 * j), u3_byte(px, 3 * j + 1),
-                                                    u3_byte(px, 3 * j + 2), uy, cb, cr);
+                            JmFwdTies tie;
+                            const float p0 = (float)u3_byte(px, 3 * j), p1 = (float)u3_byte(px, 3 * j + 1),
+                                        p2 = (float)u3_byte(px, 3 * j + 2);
+                            jm_fwd_colour_fast(p0, p1, p2, uy, cb, cr, tie);
+                            if (__builtin_expect(jm_fwd_any_tie(tie), 0)) // an exact x.5 somewhere: ask the doubles
+                                jm_fwd_colour_fix(p0, p1, p2, tie, uy, cb, cr);
                             (row ? yb : ya)[j] = uy;
                             sum_b[j >> 1] += cb;
                             sum_r[j >> 1] += cr;
@@ -350,29 +350,14 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
                     const int crow = (it - 1) * 4 + rp;
                     uint32_t cbp = *reinterpret_cast<const uint16_t *>(cbuf + crow * 256 + 2 * g);
                     uint32_t crp = *reinterpret_cast<const uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g);
-                    uint8_t oa[12], ob[12];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        // upsampleChroma: (i/2, j/2), encode_decode.cpp:165-170
-                        const int cb = (int)((cbp >> (8 * h)) & 0xFFu), cr = (int)((crp >> (8 * h)) & 0xFFu);
-                        const JmChromaTerm ct = jm_inv_chroma(cb, cr);
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = 2 * h + jj;
-                            int o0, o1, o2;
-                            jm_inv_colour((int)((ya >> (8 * j)) & 0xFFu), cb, cr, ct, o0, o1, o2);
-                            oa[3 * j] = (uint8_t)o0, oa[3 * j + 1] = (uint8_t)o1, oa[3 * j + 2] = (uint8_t)o2;
-                            jm_inv_colour((int)((yb >> (8 * j)) & 0xFFu), cb, cr, ct, o0, o1, o2);
-                            ob[3 * j] = (uint8_t)o0, ob[3 * j + 1] = (uint8_t)o1, ob[3 * j + 2] = (uint8_t)o2;
-                        }
-                    }
+                    // upsampleChroma: (i/2, j/2), encode_decode.cpp:165-170 -- each chroma
+                    // sample serves a 2x2 quad, i.e. two pixels in each of the two rows
+                    const int cb0 = (int)(cbp & 0xFFu), cb1 = (int)(cbp >> 8);
+                    const int cr0 = (int)(crp & 0xFFu), cr1 = (int)(crp >> 8);
+                    const JmChromaPk c0 = jm_inv_chroma_pk(cb0, cr0), c1 = jm_inv_chroma_pk(cb1, cr1);
                     U3 wa, wb;
-                    wa.a = oa[0] | (oa[1] << 8) | (oa[2] << 16) | ((uint32_t)oa[3] << 24);
-                    wa.b = oa[4] | (oa[5] << 8) | (oa[6] << 16) | ((uint32_t)oa[7] << 24);
-                    wa.c = oa[8] | (oa[9] << 8) | (oa[10] << 16) | ((uint32_t)oa[11] << 24);
-                    wb.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | ((uint32_t)ob[3] << 24);
-                    wb.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | ((uint32_t)ob[7] << 24);
-                    wb.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | ((uint32_t)ob[11] << 24);
+                    jm_inv_row4(ya, c0, c1, cb0, cr0, cb1, cr1, wa.a, wa.b, wa.c);
+                    jm_inv_row4(yb, c0, c1, cb0, cr0, cb1, cr1, wb.a, wb.b, wb.c);
                     uint8_t *p0 = bgr + (size_t)(row_base + 2 * rp) * stride + (size_t)x * 3;
                     *reinterpret_cast<U3 *>(p0) = wa;
                     *reinterpret_cast<U3 *>(p0 + stride) = wb;

@@ -381,33 +381,64 @@ JM_HD uint32_t jm_pack4_u8(float a, float b, float c, float d)
 // numerators (< 2^24) times 1e-4 (error < 2e-5, ties 1e-4 apart).  A value is a
 // tie candidate when its distance to the nearest integer exceeds the threshold;
 // `tie` collects the sign bits of (threshold - distance).
-JM_HD void jm_fwd_colour_fast(float p0, float p1, float p2, float &uy, float &cb, float &cr, uint32_t &tie)
+struct JmFwdTies {
+    float sy, sb, sr; // the unrounded float values (Y, Cb, Cr)
+    float ty, tb, tr; // sign bit set: that channel is an exact-tie candidate
+};
+
+JM_HD void jm_fwd_colour_fast(float p0, float p1, float p2, float &uy, float &cb, float &cr, JmFwdTies &t)
 {
-    float sy = jm_fma(p2, 0.114f, jm_fma(p1, 0.587f, p0 * 0.299f));
-    uy = sy + JM_MAGIC;
-    float ry = sy - (uy - JM_MAGIC);
+    t.sy = jm_fma(p2, 0.114f, jm_fma(p1, 0.587f, p0 * 0.299f));
+    uy = t.sy + JM_MAGIC;
+    float ry = t.sy - (uy - JM_MAGIC);
     float nb = jm_fma(p2, 5000.0f, jm_fma(p1, -3313.0f, jm_fma(p0, -1687.0f, 1280000.0f)));
-    float sb = nb * 1.0e-4f;
-    float ub = sb + JM_MAGIC;
-    cb = ub - JM_MAGIC;
-    float rb = sb - cb;
+    t.sb = nb * 1.0e-4f;
+    cb = (t.sb + JM_MAGIC) - JM_MAGIC;
+    float rb = t.sb - cb;
     float nr = jm_fma(p2, -813.0f, jm_fma(p1, -4187.0f, jm_fma(p0, 5000.0f, 1280000.0f)));
-    float sr = nr * 1.0e-4f;
-    float ur = sr + JM_MAGIC;
-    cr = ur - JM_MAGIC;
-    float rr = sr - cr;
-    tie |= jm_bits(0.4995f - __builtin_fabsf(ry)) | jm_bits(0.49995f - __builtin_fabsf(rb)) |
-           jm_bits(0.49995f - __builtin_fabsf(rr));
+    t.sr = nr * 1.0e-4f;
+    cr = (t.sr + JM_MAGIC) - JM_MAGIC;
+    float rr = t.sr - cr;
+    t.ty = 0.4995f - __builtin_fabsf(ry);
+    t.tb = 0.49995f - __builtin_fabsf(rb);
+    t.tr = 0.49995f - __builtin_fabsf(rr);
 }
 
-// the exact answer for one pixel, in the fast path's output form
-JM_HD void jm_fwd_colour_exact(int p0, int p1, int p2, float &uy, float &cb, float &cr)
+JM_HD bool jm_fwd_any_tie(const JmFwdTies &t)
 {
-    int y, b, r;
-    jm_fwd_colour(p0, p1, p2, y, b, r);
-    uy = (float)y + JM_MAGIC;
-    cb = (float)b;
-    cr = (float)r;
+    return (int32_t)(jm_bits(t.ty) | jm_bits(t.tb) | jm_bits(t.tr)) < 0;
+}
+
+// Exact ties: the value is k + 0.5 as a rational (k = floor of the float value,
+// which is within 1e-4 of k + 0.5); the reference's double sequence
+// (encode_decode.cpp:58-63, one rounding per operation, no contraction) lands on,
+// above or below it, and round() goes up unless it is below.
+JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, float &uy, float &cb, float &cr)
+{
+    const double d0 = (double)p0, d1 = (double)p1, d2 = (double)p2;
+    if ((int32_t)jm_bits(t.ty) < 0) {
+        double v = 0.299 * d0; // 0.0 + x is exact
+        v = v + 0.587 * d1;
+        v = v + 0.114 * d2;
+        float k = ((t.sy - 0.5f) + JM_MAGIC) - JM_MAGIC;
+        uy = (v >= (double)k + 0.5 ? k + 1.0f : k) + JM_MAGIC;
+    }
+    if ((int32_t)jm_bits(t.tb) < 0) {
+        double v = 128.0 + -0.1687 * d0;
+        v = v + -0.3313 * d1;
+        v = v + 0.5 * d2;
+        float k = ((t.sb - 0.5f) + JM_MAGIC) - JM_MAGIC;
+        cb = v >= (double)k + 0.5 ? k + 1.0f : k;
+        cb = cb == 256.0f ? 0.0f : cb; // static_cast<uchar>(256.0) wraps (:67-70)
+    }
+    if ((int32_t)jm_bits(t.tr) < 0) {
+        double v = 128.0 + 0.5 * d0;
+        v = v + -0.4187 * d1;
+        v = v + -0.0813 * d2;
+        float k = ((t.sr - 0.5f) + JM_MAGIC) - JM_MAGIC;
+        cr = v >= (double)k + 0.5 ? k + 1.0f : k;
+        cr = cr == 256.0f ? 0.0f : cr;
+    }
 }
 
 // truncating mean of four chroma values (chromaSubsampling, :139-149) as MAGIC + mean
@@ -427,4 +458,82 @@ JM_HD uint32_t jm_pack_lo8x4(float a, float b, float c, float d)
     return (jm_bits(a) & 0xFFu) | ((jm_bits(b) & 0xFFu) << 8) | ((jm_bits(c) & 0xFFu) << 16) |
            ((jm_bits(d) & 0xFFu) << 24);
 #endif
+}
+
+// ------------------------------------------------------------- inverse colour, fast
+// One chroma sample serves a 2x2 pixel quad (upsampleChroma, :165-170), so its
+// rounded contributions d0,d1,d2 (jm_inv_chroma) are packed once as int16 pairs
+// and each output row then costs one packed add + one saturating pack per two
+// output bytes: B0 G0 | R0 B1 | G1 R1 for a pixel pair.
+struct JmChromaPk {
+    uint32_t d01, d20, d12; // {d0,d1}, {d2,d0}, {d1,d2} as int16 pairs (first in the low half)
+    int tie;                // jm_inv_chroma's tie bits
+};
+
+JM_HD JmChromaPk jm_inv_chroma_pk(int cb, int cr)
+{
+    const JmChromaTerm t = jm_inv_chroma(cb, cr);
+    JmChromaPk p;
+    p.d01 = jm_pack_lo16((uint32_t)t.d0, (uint32_t)t.d1);
+    p.d20 = jm_pack_lo16((uint32_t)t.d2, (uint32_t)t.d0);
+    p.d12 = jm_pack_lo16((uint32_t)t.d1, (uint32_t)t.d2);
+    p.tie = t.tie;
+    return p;
+}
+
+// {a.lo + b.lo, a.hi + b.hi} as int16, each saturated to 0..255 -> two bytes in the low half
+JM_HD uint32_t jm_add_sat_u8x2(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short jm_s2 __attribute__((ext_vector_type(2)));
+    jm_s2 s = __builtin_bit_cast(jm_s2, a) + __builtin_bit_cast(jm_s2, b);
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, s)));
+    return r;
+#else
+    int lo = (int16_t)(a & 0xFFFFu) + (int16_t)(b & 0xFFFFu);
+    int hi = (int16_t)(a >> 16) + (int16_t)(b >> 16);
+    return (uint32_t)jm_clamp255(lo) | ((uint32_t)jm_clamp255(hi) << 8);
+#endif
+}
+
+template <int I, int J>
+JM_HD uint32_t jm_ypair(uint32_t y4) // {Y_I, Y_J} as uint16 pair from four packed Y bytes
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, y4, 0x0C000C00u | (uint32_t)I | ((uint32_t)J << 16));
+#else
+    return ((y4 >> (8 * I)) & 0xFFu) | (((y4 >> (8 * J)) & 0xFFu) << 16);
+#endif
+}
+
+// four pixels of one row (Y bytes y4), pixels 0,1 under chroma sample a and 2,3
+// under b -> 12 output bytes.  Tie pixels are redone by the reference's double
+// sequence (jm_inv_colour_f64); cba/cra/cbb/crb are only read on that path.
+JM_HD void jm_inv_row4(uint32_t y4, const JmChromaPk &a, const JmChromaPk &b,
+                       int cba, int cra, int cbb, int crb, uint32_t &w0, uint32_t &w1, uint32_t &w2)
+{
+    uint32_t h0 = jm_add_sat_u8x2(jm_ypair<0, 0>(y4), a.d01);
+    uint32_t h1 = jm_add_sat_u8x2(jm_ypair<0, 1>(y4), a.d20);
+    uint32_t h2 = jm_add_sat_u8x2(jm_ypair<1, 1>(y4), a.d12);
+    uint32_t h3 = jm_add_sat_u8x2(jm_ypair<2, 2>(y4), b.d01);
+    uint32_t h4 = jm_add_sat_u8x2(jm_ypair<2, 3>(y4), b.d20);
+    uint32_t h5 = jm_add_sat_u8x2(jm_ypair<3, 3>(y4), b.d12);
+    w0 = jm_pack_lo16(h0, h1);
+    w1 = jm_pack_lo16(h2, h3);
+    w2 = jm_pack_lo16(h4, h5);
+    if (__builtin_expect((a.tie | b.tie) != 0, 0)) {
+        uint8_t o[12];
+        for (int j = 0; j < 4; ++j) {
+            const int y = (int)((y4 >> (8 * j)) & 0xFFu);
+            const int cb = j < 2 ? cba : cbb, cr = j < 2 ? cra : crb;
+            const JmChromaTerm t = jm_inv_chroma(cb, cr);
+            int o0, o1, o2;
+            jm_inv_colour(y, cb, cr, t, o0, o1, o2);
+            o[3 * j] = (uint8_t)o0, o[3 * j + 1] = (uint8_t)o1, o[3 * j + 2] = (uint8_t)o2;
+        }
+        w0 = o[0] | (o[1] << 8) | (o[2] << 16) | ((uint32_t)o[3] << 24);
+        w1 = o[4] | (o[5] << 8) | (o[6] << 16) | ((uint32_t)o[7] << 24);
+        w2 = o[8] | (o[9] << 8) | (o[10] << 16) | ((uint32_t)o[11] << 24);
+    }
 }

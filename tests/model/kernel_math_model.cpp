@@ -36,11 +36,12 @@ void jmm_fwd_colour_fast(const uint8_t *src, size_t n, uint8_t *dst, long *n_can
     long cand = 0;
     for (size_t i = 0; i < n; ++i) {
         float uy, cb, cr;
-        uint32_t tie = 0;
-        jm_fwd_colour_fast((float)src[3 * i], (float)src[3 * i + 1], (float)src[3 * i + 2], uy, cb, cr, tie);
-        if ((int32_t)tie < 0) {
+        JmFwdTies tie;
+        const float p0 = (float)src[3 * i], p1 = (float)src[3 * i + 1], p2 = (float)src[3 * i + 2];
+        jm_fwd_colour_fast(p0, p1, p2, uy, cb, cr, tie);
+        if (jm_fwd_any_tie(tie)) {
             ++cand;
-            jm_fwd_colour_exact(src[3 * i], src[3 * i + 1], src[3 * i + 2], uy, cb, cr);
+            jm_fwd_colour_fix(p0, p1, p2, tie, uy, cb, cr);
         }
         dst[3 * i] = (uint8_t)(jm_bits(uy) & 0xFFu);
         dst[3 * i + 1] = (uint8_t)(int)cb;
@@ -58,6 +59,20 @@ void jmm_inv_colour(const uint8_t *src, size_t n, uint8_t *dst)
         dst[3 * i] = (uint8_t)o0;
         dst[3 * i + 1] = (uint8_t)o1;
         dst[3 * i + 2] = (uint8_t)o2;
+    }
+}
+
+// the kernels' row path: n groups of 4 pixels, each group = 4 Y bytes + two chroma
+// samples (cb,cr for pixels 0-1 and for pixels 2-3) -> 12 bytes
+void jmm_inv_rows(const uint8_t *y, const uint8_t *cbcr, size_t n, uint8_t *dst)
+{
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t y4, w[3];
+        std::memcpy(&y4, y + 4 * i, 4);
+        const int cba = cbcr[4 * i], cra = cbcr[4 * i + 1], cbb = cbcr[4 * i + 2], crb = cbcr[4 * i + 3];
+        JmChromaPk a = jm_inv_chroma_pk(cba, cra), b = jm_inv_chroma_pk(cbb, crb);
+        jm_inv_row4(y4, a, b, cba, cra, cbb, crb, w[0], w[1], w[2]);
+        std::memcpy(dst + 12 * i, w, 12);
     }
 }
 

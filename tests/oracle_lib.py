@@ -278,6 +278,14 @@ class KernelMathModel:
         self.lib.jmm_inv_colour(_p(img), C.c_size_t(img.size // 3), _p(out))
         return out
 
+    def inv_rows(self, y4, cbcr):
+        """y4: [n, 4] Y bytes; cbcr: [n, 4] = cb_a, cr_a, cb_b, cr_b -> [n, 4, 3] output bytes"""
+        y4 = np.ascontiguousarray(y4, np.uint8)
+        cbcr = np.ascontiguousarray(cbcr, np.uint8)
+        out = np.empty((y4.shape[0], 4, 3), np.uint8)
+        self.lib.jmm_inv_rows(_p(y4), _p(cbcr), C.c_size_t(y4.shape[0]), _p(out))
+        return out
+
     def fdct_quant_blocks(self, px, q):
         px = np.ascontiguousarray(px, np.int32).reshape(-1, 64)
         out = np.empty_like(px)

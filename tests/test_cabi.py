@@ -43,3 +43,15 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 text = open(os.path.join(base, f), errors="replace").read()
                 assert "liboracle" not in text and "orc_" not in text and "libjmmodel" not in text, f
+
+
+def test_kernel_cuh_symbols_are_exported():
+    """the reference's C++ boundary (kernel.cuh:6-10): exact mangled names, so that its
+    main.o / analysis.o link against libjpeg_amd_kernelcuh.so instead of kernel.o"""
+    import subprocess
+    so = os.path.join(ROOT, "jpeg_amd", "libjpeg_amd_kernelcuh.so")
+    names = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    # void dctQuantizationParallel(const vector<vector<vector<int>>>&, const vector<vector<int>>&, vector<vector<float>>&)
+    assert "_Z23dctQuantizationParallelRKSt6vectorIS_IS_IiSaIiEESaIS1_EESaIS3_EERKS3_RS_IS_IfSaIfEESaISB_EE" in names
+    # void dequantizeInverseDCTParallel(const vector<vector<vector<float>>>&, const vector<vector<int>>&, vector<vector<vector<int>>>&)
+    assert "_Z28dequantizeInverseDCTParallelRKSt6vectorIS_IS_IfSaIfEESaIS1_EESaIS3_EERKS_IS_IiSaIiEESaIS9_EERS_ISB_SaISB_EE" in names

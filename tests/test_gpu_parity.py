@@ -181,6 +181,30 @@ def test_legacy_blocks_boundary(gpu, orc, model):
     assert jpeg_amd.fdct_quant_blocks(np.zeros((0, 64), np.int32), q).shape == (0, 64)
 
 
+def test_kernel_cuh_cpp_symbols(gpu, orc, tmp_path):
+    """the reference's own call shape (encode_decode.cpp:728 / :790): nested std::vector in,
+    callee-sized nested std::vector out, through libjpeg_amd_kernelcuh.so"""
+    import subprocess
+    import jpeg_amd
+    driver = os.path.join(os.path.dirname(GOLD), "cpp", "kernel_cuh_driver")
+    rng = np.random.default_rng(11)
+    nb = 300
+    px = rng.integers(0, 256, (nb, 64)).astype(np.int32)
+    q = jpeg_amd.quality_tables(60)[0]
+    want = np.stack([orc.quantize_block(orc.dct_block(p - 128), q) for p in px])
+    inp = tmp_path / "in.bin"
+    out = tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(np.int32(nb).tobytes() + q.astype(np.int32).tobytes() + px.tobytes() + want.astype(np.float32).tobytes())
+    subprocess.check_call([driver, str(inp), str(out)])
+    raw = open(out, "rb").read()
+    got_q = np.frombuffer(raw[:nb * 256], np.float32).reshape(nb, 64)
+    got_px = np.frombuffer(raw[nb * 256:], np.int32).reshape(nb, 64)
+    _check_coef(got_q.astype(np.int32), want.astype(np.int32), "kernel.cuh encode")
+    ref = np.stack([orc.idct_block(w * q.astype(np.float32)) + 128 for w in want])
+    _check_px(got_px, ref, "kernel.cuh decode")
+
+
 def test_wikipedia_block(gpu):
     """known answers of jpeg_concept/jpeg_function.cpp:486-495 at QF=50."""
     import json

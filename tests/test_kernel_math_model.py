@@ -66,3 +66,19 @@ def test_transform_mismatch_rate_on_lena(model, orc, lena_bgr, qf):
     assert pbad <= 40 * ptot // 1_000_000 + 1, (pbad, ptot)
     if qf == 50:
         assert nbad == 0  # hence a byte-identical .bin on the golden input
+
+
+def test_inverse_colour_row_path_all_triples(model, orc):
+    """the packed-int16 row path of the decoder: every (Y, Cb, Cr), in both chroma slots"""
+    cb, cr = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    cb, cr = cb.reshape(-1), cr.reshape(-1)
+    for y0 in range(0, 256, 4):
+        y4 = np.tile(np.arange(y0, y0 + 4, dtype=np.uint8), (cb.size, 1))
+        # slot a = (cb, cr), slot b = the transposed pair, so both slots see all pairs
+        cbcr = np.stack([cb, cr, cr, cb], -1).astype(np.uint8)
+        got = model.inv_rows(y4, cbcr)
+        ycc = np.empty((cb.size, 4, 3), np.uint8)
+        ycc[:, :, 0] = y4
+        ycc[:, :2, 1], ycc[:, :2, 2] = cb[:, None], cr[:, None]
+        ycc[:, 2:, 1], ycc[:, 2:, 2] = cr[:, None], cb[:, None]
+        assert np.array_equal(got, orc.ycbcr2rgb(ycc))
