@@ -70,7 +70,7 @@ __device__ __forceinline__ int u3_byte(const U3 &v, int idx)
 // coefficient i (natural order): the int16 value sits in the low 16 bits.
 // Straight-line code on purpose: with no branch in it the scheduler keeps the
 // whole transform near 80 VGPRs.
-__device__ __forceinline__ void block_fdct_quant(float (&v)[64], const QuantConsts &qc)
+__device__ __forceinline__ void block_fdct_quant(float (&v)[64], const float *inv100q)
 {
 #pragma unroll
     for (int r = 0; r < 8; ++r)
@@ -80,7 +80,7 @@ __device__ __forceinline__ void block_fdct_quant(float (&v)[64], const QuantCons
     for (int c = 0; c < 8; ++c)
         jm_fdct8<100, false>(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
                              v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
-    jm_quantise_block(v, qc);
+    jm_quantise_block(v, inv100q);
 }
 
 // v: 64 dequantised coefficients (natural order) on entry; on exit v[i] = MAGIC +
@@ -118,7 +118,7 @@ __device__ __forceinline__ void stage_write_zigzag(const float (&qv)[64], uint8_
 
 // 128 staged bytes (zigzag int16) -> dequantised floats in natural order
 __device__ __forceinline__ void stage_read_dequant(const uint8_t *stage, int lane, float (&v)[64],
-                                                   const QuantConsts &qc)
+                                                   const float *q)
 {
     const uint4 *src = reinterpret_cast<const uint4 *>(stage + lane * kStagePitch);
 #pragma unroll
@@ -130,8 +130,8 @@ __device__ __forceinline__ void stage_read_dequant(const uint8_t *stage, int lan
             int i = (k * 4 + j) * 2;
             int lo = (int)(int16_t)(w[j] & 0xFFFFu);
             int hi = (int)w[j] >> 16;
-            v[kZZ[i]] = (float)lo * qc.q[kZZ[i]];         // encode_decode.cpp:564 / kernel.cu:175
-            v[kZZ[i + 1]] = (float)hi * qc.q[kZZ[i + 1]];
+            v[kZZ[i]] = (float)lo * q[kZZ[i]];         // encode_decode.cpp:564 / kernel.cu:175
+            v[kZZ[i + 1]] = (float)hi * q[kZZ[i + 1]];
         }
     }
 }
@@ -144,11 +144,17 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     int tiles_x, int n_tiles)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kWaveLds];
+    // quantiser multipliers as an LDS table (broadcast b128 reads): 128 SGPRs of
+    // kernel arguments would not fit next to the transform
+    __shared__ __attribute__((aligned(16))) float qtab[128];
+    if (threadIdx.x < 128)
+        qtab[threadIdx.x] = qp.t[threadIdx.x >> 6].inv100q[threadIdx.x & 63];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * kWavesPerWg + wave;
     if (tile >= n_tiles)
-        return; // whole wave leaves together; nothing is shared between waves
+        return; // whole wave leaves together; nothing else is shared between waves
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     uint8_t *stage = lds + wave * kWaveLds; // Y rows (8 x 512) alias the staging area
     uint8_t *cbuf = stage + kStageBytes;    // Cb: 8 x 256, Cr: 8 x 256
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                     v[r * 8 + 4 + j] = (float)((d.y >> (8 * j)) & 0xFFu);
                 }
             }
-            block_fdct_quant(v, qp.t[luma ? 0 : 1]);
+            block_fdct_quant(v, qtab + (luma ? 0 : 64));
             // The staging area aliases the Y rows.  LDS instructions of one wave
             // retire in program order, so every lane's reads above are done before
             // the writes below; the fence only pins the compiler's order.
@@ -280,6 +286,10 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     uint8_t *__restrict__ bgr, size_t stride, int tiles_x, int n_tiles)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kWaveLds];
+    __shared__ __attribute__((aligned(16))) float qtab[128]; // Q as floats: luma, chroma
+    if (threadIdx.x < 128)
+        qtab[threadIdx.x] = qp.t[threadIdx.x >> 6].q[threadIdx.x & 63];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * kWavesPerWg + wave;
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
         const bool valid = bcol < (luma ? bw_y : bw_c);
         if (valid) {
             float v[64];
-            stage_read_dequant(stage, lane, v, qp.t[luma ? 0 : 1]);
+            stage_read_dequant(stage, lane, v, qtab + (luma ? 0 : 64));
             block_idct(v);
             wave_lds_fence(); // staged coefficients consumed (in-order LDS): Y rows may overwrite them
             uint8_t *dst = luma ? stage + lane * 8 : cbuf + (lane >> 5) * 2048 + (lane & 31) * 8;
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(256) void encode_plane_kernel(
                                        ? (float)plane[(size_t)(r0 + r) * stride + c0 + c]
                                        : 0.0f;
         }
-        block_fdct_quant(v, qc);
+        block_fdct_quant(v, qc.inv100q);
         stage_write_zigzag(v, stage, lane);
     }
     wave_lds_fence();
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(256) void decode_plane_kernel(
     const int bx = gx * 64 + lane;
     if (bx < bw) {
         float v[64];
-        stage_read_dequant(stage, lane, v, qc);
+        stage_read_dequant(stage, lane, v, qc.q);
         block_idct(v);
         const int r0 = by * 8, c0 = bx * 8;
         const bool interior = (r0 + 8 <= rows) && (c0 + 8 <= cols) && ((stride & 7) == 0) &&
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(256) void fdct_quant_blocks_kernel(
         int4 d = src[k];
         v[4 * k] = (float)d.x, v[4 * k + 1] = (float)d.y, v[4 * k + 2] = (float)d.z, v[4 * k + 3] = (float)d.w;
     }
-    block_fdct_quant(v, qc);
+    block_fdct_quant(v, qc.inv100q);
     float4 *dst = reinterpret_cast<float4 *>(out + b * 64);
 #pragma unroll
     for (int k = 0; k < 16; ++k) // MAGIC + q -> q (exact; +0 for 0, never -0: kernel.cu:86)

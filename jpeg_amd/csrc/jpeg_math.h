@@ -330,16 +330,17 @@ JM_HD void jm_make_quant_tab(const int32_t q[64], JmQuantTab &t)
 //       from zero (more than the float error, less than the 3.8e-6 gap), and the
 //       magic add rounds to nearest.  tests/model checks every (r, Q) pair against
 //       real float divisions.
-JM_HD void jm_quantise_block(float (&x)[64], const JmQuantTab &t)
+JM_HD void jm_quantise_block(float (&x)[64], const float *inv100q)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int i = 0; i < 64; ++i) {
         float r = (x[i] + JM_MAGIC) - JM_MAGIC;
-        x[i] = jm_fma(r, t.inv100q[i], JM_MAGIC);
+        x[i] = jm_fma(r, inv100q[i], JM_MAGIC);
     }
 }
+JM_HD void jm_quantise_block(float (&x)[64], const JmQuantTab &t) { jm_quantise_block(x, t.inv100q); }
 
 // IDCT output x = 0.25*sum (:591) -> float whose low 16 bits hold
 // round(x) + 128 as int16, with exact x.5 ties resolved toward zero like the
