@@ -257,22 +257,27 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
         wave_lds_fence();
 
         // ---- coalesced store: 64 blocks x 128 B = 8 x (64 lanes x 16 B) ------
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = k * 64 + lane;
-            const int b = j >> 3, part = j & 7;
-            int16_t *dst;
-            bool ok;
+        // piece k of lane l is bytes [16 l, 16 l + 16) of blocks 8k .. 8k+7: one
+        // uniform base per plane plus constant offsets
+        {
+            const int n_ok = luma ? bw_y - tx * 64 : bw_c - tx * 32; // blocks of this tile inside the plane
+            uint8_t *base_a, *base_b; // pieces 0-3 / 4-7
             if (luma) {
-                ok = tx * 64 + b < bw_y;
-                dst = coef_y + ((size_t)(ty * 2 + it) * bw_y + tx * 64 + b) * 64;
+                base_a = reinterpret_cast<uint8_t *>(coef_y + ((size_t)(ty * 2 + it) * bw_y + tx * 64) * 64);
+                base_b = base_a + 4096;
             } else {
-                ok = tx * 32 + (b & 31) < bw_c;
-                dst = (b >= 32 ? coef_cr : coef_cb) + ((size_t)ty * bw_c + tx * 32 + (b & 31)) * 64;
+                base_a = reinterpret_cast<uint8_t *>(coef_cb + ((size_t)ty * bw_c + tx * 32) * 64);
+                base_b = reinterpret_cast<uint8_t *>(coef_cr + ((size_t)ty * bw_c + tx * 32) * 64);
             }
-            if (ok) {
-                uint4 d = *reinterpret_cast<const uint4 *>(stage + b * kStagePitch + part * 16);
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(dst) + part * 16) = d;
+            const int blk = lane >> 3;
+            const uint8_t *sp = stage + blk * kStagePitch + (lane & 7) * 16;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int b = (luma ? k * 8 : (k & 3) * 8) + blk; // block index within its plane's run
+                if (b < n_ok) {
+                    uint4 d = *reinterpret_cast<const uint4 *>(sp + k * 8 * kStagePitch);
+                    *reinterpret_cast<uint4 *>((k < 4 ? base_a : base_b) + (k & 3) * 1024 + lane * 16) = d;
+                }
             }
         }
         wave_lds_fence(); // staging area is free again
@@ -280,6 +285,30 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
 }
 
 // ------------------------------------------------------------- fused decoder
+__device__ __forceinline__ void fetch_coefs(int r, const int16_t *__restrict__ coef_y,
+                                            const int16_t *__restrict__ coef_cb,
+                                            const int16_t *__restrict__ coef_cr, int tx, int ty, int bw_y,
+                                            int bw_c, int lane, uint4 (&d)[8])
+{
+    const bool lum = r > 0;
+    const int blk = lane >> 3;
+    const int n_ok = lum ? bw_y - tx * 64 : bw_c - tx * 32; // blocks of this tile inside the plane
+    const uint8_t *base_a, *base_b;                          // pieces 0-3 / 4-7
+    if (lum) {
+        base_a = reinterpret_cast<const uint8_t *>(coef_y + ((size_t)(ty * 2 + r - 1) * bw_y + tx * 64) * 64);
+        base_b = base_a + 4096;
+    } else {
+        base_a = reinterpret_cast<const uint8_t *>(coef_cb + ((size_t)ty * bw_c + tx * 32) * 64);
+        base_b = reinterpret_cast<const uint8_t *>(coef_cr + ((size_t)ty * bw_c + tx * 32) * 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int b = (lum ? k * 8 : (k & 3) * 8) + blk;
+        if (b < n_ok)
+            d[k] = *reinterpret_cast<const uint4 *>((k < 4 ? base_a : base_b) + (k & 3) * 1024 + lane * 16);
+    }
+}
+
 __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     const int16_t *__restrict__ coef_y, const int16_t *__restrict__ coef_cb,
     const int16_t *__restrict__ coef_cr, int rows, int cols, QuantPair qp,
@@ -301,29 +330,30 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     const int x0 = tx * kWaveTileW;
     const int bw_y = cols >> 3, bw_c = cols >> 4;
 
-    // it = 0: the tile's 32 Cb + 32 Cr blocks; it = 1, 2: its two rows of 64 Y blocks
+    // Coefficients of round `r` (r = 0: the tile's 32 Cb + 32 Cr blocks; r = 1, 2: its two
+    // rows of 64 Y blocks) as 8 pieces of 16 B per lane: piece k of lane l is bytes
+    // [16 l, 16 l + 16) of blocks 8k .. 8k+7 -- one uniform base per plane plus constant
+    // offsets.  They are fetched one round ahead, so the HBM latency hides behind the
+    // previous round's transform.
+    const int blk = lane >> 3;
+    uint4 pre[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        pre[k] = make_uint4(0, 0, 0, 0);
+    fetch_coefs(0, coef_y, coef_cb, coef_cr, tx, ty, bw_y, bw_c, lane, pre);
+
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
         const bool luma = it > 0;
-        // ---- coalesced load of 64 blocks x 128 B into the staging area -------
+        // ---- staged coefficients: 64 blocks x 128 B at a 144 B pitch -----------
+        {
+            uint8_t *sp = stage + blk * kStagePitch + (lane & 7) * 16;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = k * 64 + lane;
-            const int b = j >> 3, part = j & 7;
-            const int16_t *src;
-            bool ok;
-            if (luma) {
-                ok = tx * 64 + b < bw_y;
-                src = coef_y + ((size_t)(ty * 2 + it - 1) * bw_y + tx * 64 + b) * 64;
-            } else {
-                ok = tx * 32 + (b & 31) < bw_c;
-                src = (b >= 32 ? coef_cr : coef_cb) + ((size_t)ty * bw_c + tx * 32 + (b & 31)) * 64;
-            }
-            if (ok) {
-                uint4 d = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(src) + part * 16);
-                *reinterpret_cast<uint4 *>(stage + b * kStagePitch + part * 16) = d;
-            }
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<uint4 *>(sp + k * 8 * kStagePitch) = pre[k];
         }
+        if (it < 2)
+            fetch_coefs(it + 1, coef_y, coef_cb, coef_cr, tx, ty, bw_y, bw_c, lane, pre);
         wave_lds_fence();
 
         // ---- transform: lane = block ---------------------------------------
@@ -364,7 +394,7 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
                     // sample serves a 2x2 quad, i.e. two pixels in each of the two rows
                     const int cb0 = (int)(cbp & 0xFFu), cb1 = (int)(cbp >> 8);
                     const int cr0 = (int)(crp & 0xFFu), cr1 = (int)(crp >> 8);
-                    const JmChromaPk c0 = jm_inv_chroma_pk(cb0, cr0), c1 = jm_inv_chroma_pk(cb1, cr1);
+                    const JmChromaPk c0 = jm_inv_chroma_pk_fast<0>(cbp, crp), c1 = jm_inv_chroma_pk_fast<1>(cbp, crp);
                     U3 wa, wb;
                     jm_inv_row4(ya, c0, c1, cb0, cr0, cb1, cr1, wa.a, wa.b, wa.c);
                     jm_inv_row4(yb, c0, c1, cb0, cr0, cb1, cr1, wb.a, wb.b, wb.c);

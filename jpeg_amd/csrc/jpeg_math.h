@@ -468,7 +468,7 @@ JM_HD uint32_t jm_pack_lo8x4(float a, float b, float c, float d)
 // output bytes: B0 G0 | R0 B1 | G1 R1 for a pixel pair.
 struct JmChromaPk {
     uint32_t d01, d20, d12; // {d0,d1}, {d2,d0}, {d1,d2} as int16 pairs (first in the low half)
-    int tie;                // jm_inv_chroma's tie bits
+    int tie;                // < 0: some pixel under this sample needs the exact path
 };
 
 JM_HD JmChromaPk jm_inv_chroma_pk(int cb, int cr)
@@ -478,7 +478,35 @@ JM_HD JmChromaPk jm_inv_chroma_pk(int cb, int cr)
     p.d01 = jm_pack_lo16((uint32_t)t.d0, (uint32_t)t.d1);
     p.d20 = jm_pack_lo16((uint32_t)t.d2, (uint32_t)t.d0);
     p.d12 = jm_pack_lo16((uint32_t)t.d1, (uint32_t)t.d2);
-    p.tie = t.tie;
+    p.tie = t.tie ? -1 : 0;
+    return p;
+}
+
+// The same three contributions from float chains.  With b = Cb-128, r = Cr-128:
+//   d0 = round(1.402 r):  the float product is within 2e-5 of the rational value,
+//        whose distance to any x.5 is at least 1e-3 (1402 r = 500 mod 1000 has no
+//        solution), so the magic add lands on the right integer;
+//   d2 = round(1.772 b):  likewise except for the exact ties at |b| = 125;
+//   d1 = round(-0.344136 b - 0.714136 r): denominators of 1e6, so anything
+//        within 1e-4 of x.5 is a candidate.
+// `tie` < 0 (sign bit) flags a candidate: jm_inv_row4 then redoes its pixels with the
+// exact integer/double path, so d1/d2 need not be right for flagged samples.
+template <int BI>
+JM_HD JmChromaPk jm_inv_chroma_pk_fast(uint32_t cbw, uint32_t crw) // byte BI of each word
+{
+    const float b = (float)((cbw >> (8 * BI)) & 0xFFu) - 128.0f;
+    const float r = (float)((crw >> (8 * BI)) & 0xFFu) - 128.0f;
+    const float u0 = jm_fma(r, 1.402f, JM_MAGIC);
+    const float u2 = jm_fma(b, 1.772f, JM_MAGIC);
+    const float f1 = jm_fma(r, -0.714136f, b * -0.344136f);
+    const float u1 = f1 + JM_MAGIC;
+    const float t1 = 0.4999f - __builtin_fabsf(f1 - (u1 - JM_MAGIC));
+    const float t2 = __builtin_fabsf(__builtin_fabsf(b) - 125.0f) - 0.5f;
+    JmChromaPk p;
+    p.d01 = jm_pack_lo16(jm_bits(u0), jm_bits(u1));
+    p.d20 = jm_pack_lo16(jm_bits(u2), jm_bits(u0));
+    p.d12 = jm_pack_lo16(jm_bits(u1), jm_bits(u2));
+    p.tie = (int)(jm_bits(t1) | jm_bits(t2));
     return p;
 }
 
@@ -523,7 +551,7 @@ JM_HD void jm_inv_row4(uint32_t y4, const JmChromaPk &a, const JmChromaPk &b,
     w0 = jm_pack_lo16(h0, h1);
     w1 = jm_pack_lo16(h2, h3);
     w2 = jm_pack_lo16(h4, h5);
-    if (__builtin_expect((a.tie | b.tie) != 0, 0)) {
+    if (__builtin_expect((a.tie | b.tie) < 0, 0)) {
         uint8_t o[12];
         for (int j = 0; j < 4; ++j) {
             const int y = (int)((y4 >> (8 * j)) & 0xFFu);

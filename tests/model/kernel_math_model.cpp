@@ -70,7 +70,9 @@ void jmm_inv_rows(const uint8_t *y, const uint8_t *cbcr, size_t n, uint8_t *dst)
         uint32_t y4, w[3];
         std::memcpy(&y4, y + 4 * i, 4);
         const int cba = cbcr[4 * i], cra = cbcr[4 * i + 1], cbb = cbcr[4 * i + 2], crb = cbcr[4 * i + 3];
-        JmChromaPk a = jm_inv_chroma_pk(cba, cra), b = jm_inv_chroma_pk(cbb, crb);
+        // the kernels' float chroma terms, bytes packed as the kernel reads them
+        const uint32_t cbw = (uint32_t)cba | ((uint32_t)cbb << 8), crw = (uint32_t)cra | ((uint32_t)crb << 8);
+        JmChromaPk a = jm_inv_chroma_pk_fast<0>(cbw, crw), b = jm_inv_chroma_pk_fast<1>(cbw, crw);
         jm_inv_row4(y4, a, b, cba, cra, cbb, crb, w[0], w[1], w[2]);
         std::memcpy(dst + 12 * i, w, 12);
     }
@@ -114,6 +116,28 @@ void jmm_dequant_idct_blocks(const int32_t *coef, size_t nb, const int32_t *q, i
         for (int i = 0; i < 64; ++i)
             out[b * 64 + i] = jm_magic_to_int(jm_pixel_magic(v[i]));
     }
+}
+
+// all 65536 (cb, cr): the float chroma terms equal the exact ones wherever they are
+// not flagged, and every exact tie is flagged.  Returns #failures; *n_flagged counts
+// the candidates.
+long jmm_check_inv_chroma_fast(long *n_flagged)
+{
+    long bad = 0, fl = 0;
+    for (int cb = 0; cb < 256; ++cb)
+        for (int cr = 0; cr < 256; ++cr) {
+            const JmChromaPk e = jm_inv_chroma_pk(cb, cr);
+            const JmChromaPk f = jm_inv_chroma_pk_fast<0>((uint32_t)cb, (uint32_t)cr);
+            const JmChromaPk g = jm_inv_chroma_pk_fast<1>((uint32_t)cb << 8, (uint32_t)cr << 8);
+            if (f.tie < 0)
+                ++fl;
+            else
+                bad += f.d01 != e.d01 || f.d20 != e.d20 || f.d12 != e.d12;
+            bad += e.tie < 0 && f.tie >= 0;
+            bad += f.d01 != g.d01 || f.d20 != g.d20 || f.d12 != g.d12 || (f.tie < 0) != (g.tie < 0);
+        }
+    *n_flagged = fl;
+    return bad;
 }
 
 const uint8_t *jmm_zigzag(void) { return kZigzag; }

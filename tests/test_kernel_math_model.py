@@ -13,6 +13,15 @@ def test_arithmetic_shortcuts_are_exact(model):
     assert model.lib.jmm_check_quant((1 << 18) - 1) == 0   # snap + quantise vs real float divisions, all (r, Q)
 
 
+def test_inverse_chroma_terms_float_path(model):
+    """All 65536 (Cb, Cr): the decoder's float chroma terms equal the exact integer
+    ones unless flagged for the exact path, every true tie is flagged, and few are."""
+    import ctypes
+    n = ctypes.c_long(0)
+    assert model.lib.jmm_check_inv_chroma_fast(ctypes.byref(n)) == 0
+    assert 0 < n.value < 65536 // 50
+
+
 @pytest.mark.slow
 def test_round_half_away_every_float(model):
     assert model.lib.jmm_check_round() == 0          # every float below 2^22, both signs
