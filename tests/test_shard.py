@@ -1,0 +1,125 @@
+"""MCU-row strip sharding (jpeg_amd/shard.py).
+
+CPU: the partition's arithmetic, and a world_size-2 gloo run in which each rank
+encodes its strip (the oracle stands in for the GPU: this tests the host logic
+and the exchange, not the kernels) and the gathered planes must equal the
+whole-image encode bit for bit.  GPU: the same with virtual ranks on one card,
+through the real kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from jpeg_amd import shard
+from jpeg_amd.synth import synth_image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_strip_partition_covers_image_once():
+    for rows in (16, 32, 48, 1024, 2160 // 16 * 16, 8192):
+        for world in (1, 2, 3, 4, 7, 8, 600):
+            edges = [shard.strip_rows(rows, world, g) for g in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == rows
+            for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+                assert a1 == b0 and a0 <= a1
+            sizes = [(b - a) // 16 for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1 and all(a % 16 == 0 for a, _ in edges)
+    with pytest.raises(ValueError):
+        shard.strip_rows(100, 2, 0)
+    with pytest.raises(ValueError):
+        shard.strip_rows(64, 2, 2)
+
+
+def test_split_planes_is_block_raster_order():
+    rows, cols, world = 80, 64, 3
+    ny, nc = (rows // 8) * (cols // 8), (rows // 16) * (cols // 16)
+    cy = torch.arange(ny).reshape(-1, 1).repeat(1, 64)
+    cb = torch.arange(nc).reshape(-1, 1).repeat(1, 64)
+    got_y, got_c = [], []
+    for g in range(world):
+        sy, scb, scr = shard.split_planes(cy, cb, cb, rows, cols, world, g)
+        r0, r1 = shard.strip_rows(rows, world, g)
+        assert sy.shape[0] == (r1 - r0) // 8 * (cols // 8) and scb.shape[0] == (r1 - r0) // 16 * (cols // 16)
+        got_y.append(sy)
+        got_c.append(scb)
+    assert torch.equal(torch.cat(got_y), cy) and torch.equal(torch.cat(got_c), cb)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, rows, cols, result_path):
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    import oracle_lib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.Oracle()
+        qy, qc = orc.quality_tables(50)
+        img = synth_image(rows, cols, 7, "photo").numpy()
+        r0, r1 = shard.strip_rows(rows, world, rank)
+        if r1 > r0:
+            sy, scb, scr = (torch.from_numpy(a) for a in orc.encode_image(img[r0:r1], qy, qc, threads=2))
+        else:
+            sy = scb = scr = torch.empty((0, 64), dtype=torch.int16)
+        gy, gcb, gcr = shard.gather_planes(sy, scb, scr, rows, cols)
+        # decode side: every rank slices its strip back out of the whole planes
+        by, bcb, bcr = shard.split_planes(gy, gcb, gcr, rows, cols, world, rank)
+        ok_back = torch.equal(by, sy) and torch.equal(bcb, scb) and torch.equal(bcr, scr)
+        if rank == 0:
+            wy, wcb, wcr = orc.encode_image(img, qy, qc, threads=2)
+            ok = (np.array_equal(gy.numpy(), wy) and np.array_equal(gcb.numpy(), wcb)
+                  and np.array_equal(gcr.numpy(), wcr))
+            with open(result_path, "w") as f:
+                f.write("ok" if ok and ok_back else "mismatch")
+        flag = torch.tensor([1 if ok_back else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        assert int(flag) == 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows", [96, 112])  # 6 and 7 MCU rows: even and uneven strips
+def test_gloo_world2_gather_equals_whole_image(tmp_path, rows):
+    import torch.multiprocessing as mp
+    world, cols = 2, 160
+    result = tmp_path / "result.txt"
+    mp.spawn(_gloo_worker, args=(world, _free_port(), rows, cols, str(result)), nprocs=world, join=True)
+    assert result.read_text() == "ok"
+
+
+def test_gloo_world3_with_an_empty_rank(tmp_path):
+    import torch.multiprocessing as mp
+    result = tmp_path / "result.txt"
+    mp.spawn(_gloo_worker, args=(3, _free_port(), 32, 64, str(result)), nprocs=3, join=True)
+    assert result.read_text() == "ok"
+
+
+@pytest.mark.gpu
+def test_virtual_ranks_on_one_gpu_equal_whole_image(gpu):
+    """G strips encoded independently by the kernels concatenate to the whole-image
+    planes bit for bit, and strip decodes tile the whole-image decode."""
+    import jpeg_amd
+    rows, cols = 1072, 1040  # 67 MCU rows, partial 512-px tiles
+    qy, qc = jpeg_amd.quality_tables(50)
+    img = synth_image(rows, cols, 11, "photo", device=gpu)
+    whole = jpeg_amd.encode_image(img, qy, qc)
+    rec = jpeg_amd.decode_image(*whole, rows, cols, qy, qc)
+    for world in (2, 3, 8):
+        parts = []
+        for g in range(world):
+            r0, r1 = shard.strip_rows(rows, world, g)
+            parts.append(jpeg_amd.encode_image(img[r0:r1].contiguous(), qy, qc))
+            s = shard.split_planes(*whole, rows, cols, world, g)
+            strip = jpeg_amd.decode_image(*(t.contiguous() for t in s), r1 - r0, cols, qy, qc)
+            assert torch.equal(strip, rec[r0:r1])
+        for k in range(3):
+            assert torch.equal(torch.cat([p[k] for p in parts]), whole[k])
