@@ -90,6 +90,28 @@ int jpegamd_decode_image(const int16_t *coef_y, const int16_t *coef_cb, const in
                          int rows, int cols, const int32_t q_luma[64],
                          const int32_t q_chroma[64], uint8_t *bgr, size_t stride);
 
+/* ---- run-length stage ----------------------------------------------------- */
+/* Bytes of device workspace the two calls below need for a plane of nb blocks. */
+size_t jpegamd_rle_workspace_bytes(size_t nb);
+/* run_length_encode over a whole plane, encode_decode.cpp:350-373 applied block by
+ * block in raster order (:643-645): d_coef_zz = nb x 64 int16 in zigzag order (the
+ * output of the encode calls above) -> d_pairs = (value, run) int32 pairs, the
+ * memory layout of the reference's std::vector<int>; d_block_offsets[b] = index of
+ * block b's first pair, d_block_offsets[nb] = total number of pairs (nb + 1 uint32).
+ * Pairs beyond cap_pairs are not written (the total still is): size the buffer
+ * for nb*64 pairs, or call again when the total exceeds the capacity.
+ * DEVICE pointers, three launches on `stream`, no allocation. */
+int jpegamd_rle_encode_plane_dev(const int16_t *d_coef_zz, size_t nb, int32_t *d_pairs, size_t cap_pairs,
+                                 uint32_t *d_block_offsets, void *d_workspace, size_t workspace_bytes,
+                                 void *stream);
+/* decodeRLE, encode_decode.cpp:484-518: n_pairs (value, run) int32 pairs expanded
+ * into one sequence cut every 64 values -> nb x 64 int16.  Values that would fall
+ * beyond block nb-1 are dropped (the trailing pad symbols of loadEncodedData,
+ * encode_decode.cpp:1261-1263, which the reference discards at :702); blocks the
+ * stream does not reach are zero; non-positive runs expand to nothing. */
+int jpegamd_rle_decode_plane_dev(const int32_t *d_pairs, size_t n_pairs, size_t nb, int16_t *d_coef_zz,
+                                 void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Times `iters` back-to-back launches of encode followed by decode on `stream`
  * with HIP events recorded on that same stream; writes the mean milliseconds
  * per launch of each kernel.  Used by bench.py for the roofline figures. */

@@ -6,4 +6,5 @@ from .api import (  # noqa: F401
     quality_tables, analysis_tables, init,
     encode_image, decode_image, encode_plane, decode_plane,
     fdct_quant_blocks, dequant_idct_blocks, time_image, ZIGZAG,
+    rle_encode_plane, rle_decode_plane,
 )

@@ -30,6 +30,10 @@ SIGNATURES = {
                              _c.c_void_p, _c.c_void_p, _c.c_void_p],
     "jpegamd_decode_image": [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
                              _c.c_void_p, _c.c_void_p, _c.c_size_t],
+    "jpegamd_rle_encode_plane_dev": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                                     _c.c_size_t, _c.c_void_p],
+    "jpegamd_rle_decode_plane_dev": [_c.c_void_p, _c.c_size_t, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                                     _c.c_size_t, _c.c_void_p],
     "jpegamd_time_image_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                _c.POINTER(_c.c_float), _c.POINTER(_c.c_float)],
@@ -55,6 +59,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.argtypes = argtypes
             fn.restype = _c.c_int
+        lib.jpegamd_rle_workspace_bytes.argtypes = [_c.c_size_t]
+        lib.jpegamd_rle_workspace_bytes.restype = _c.c_size_t
         lib.jpegamd_last_error.argtypes = []
         lib.jpegamd_last_error.restype = _c.c_char_p
         _lib = lib

@@ -162,3 +162,37 @@ def time_image(bgr, coefs, bgr_out, q_luma, q_chroma, iters, stream=None):
         _dev(bgr_out, torch.uint8, "bgr_out"), int(iters), _stream(stream),
         ctypes.byref(e), ctypes.byref(d)))
     return e.value, d.value
+
+
+def rle_encode_plane(coef, stream=None):
+    """run_length_encode over a zigzag coefficient plane (encode_decode.cpp:350-373,
+    :643-645): cuda int16 [nb, 64] -> (pairs cuda int32 [n, 2] = (value, run),
+    block_offsets cuda int32 [nb + 1]) via jpegamd_rle_encode_plane_dev."""
+    import torch
+    lib = _lib.load()
+    nb = int(coef.shape[0])
+    src = _dev(coef, torch.int16, "rle_encode_plane")
+    work = torch.empty(lib.jpegamd_rle_workspace_bytes(nb), dtype=torch.uint8, device=coef.device)
+    offs = torch.empty(nb + 1, dtype=torch.int32, device=coef.device)
+    cap = min(nb * 64, max(1024, nb * 12))  # typical planes need far less than the worst case
+    while True:
+        pairs = torch.empty((cap, 2), dtype=torch.int32, device=coef.device)
+        _lib.check(lib.jpegamd_rle_encode_plane_dev(src, nb, pairs.data_ptr(), cap, offs.data_ptr(),
+                                                    work.data_ptr(), work.numel(), _stream(stream)))
+        total = int(offs[nb].item()) & 0xFFFFFFFF
+        if total <= cap:
+            return pairs[:total], offs
+        cap = total
+
+
+def rle_decode_plane(pairs, nb, stream=None):
+    """decodeRLE (encode_decode.cpp:484-518): cuda int32 [n, 2] pairs -> cuda int16 [nb, 64]."""
+    import torch
+    lib = _lib.load()
+    n = int(pairs.shape[0])
+    src = _dev(pairs, torch.int32, "rle_decode_plane") if n else 0
+    work = torch.empty(lib.jpegamd_rle_workspace_bytes(nb), dtype=torch.uint8, device=pairs.device)
+    out = torch.empty((nb, 64), dtype=torch.int16, device=pairs.device)
+    _lib.check(lib.jpegamd_rle_decode_plane_dev(src, n, int(nb), out.data_ptr(), work.data_ptr(),
+                                                work.numel(), _stream(stream)))
+    return out

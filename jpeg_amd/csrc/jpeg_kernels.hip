@@ -23,6 +23,7 @@
 
 #include "../../include/jpeg_amd.h"
 #include "jpeg_math.h"
+#include "host_common.h"
 
 namespace {
 
@@ -561,23 +562,8 @@ __global__ __launch_bounds__(256) void dequant_idct_blocks_kernel(
 }
 
 // ------------------------------------------------------------------ host side
-thread_local char g_err[512] = "";
-
-int fail(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return 1;
-}
-
-#define HIPCHK(expr)                                                                         \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+#define fail(...) jpegamd_fail(__VA_ARGS__)
+#define HIPCHK(expr) JPEGAMD_HIPCHK(expr)
 
 int make_consts(const int32_t q[64], QuantConsts &c, const char *what)
 {
@@ -615,9 +601,20 @@ struct DevBuf { // host-pointer entry points: per-call device memory
 
 } // namespace
 
+static thread_local char g_err[512] = "";
+
+int jpegamd_fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
 extern "C" {
 
-int jpegamd_abi_version(void) { return 1; }
+int jpegamd_abi_version(void) { return 2; }
 
 const char *jpegamd_last_error(void) { return g_err; }
 
