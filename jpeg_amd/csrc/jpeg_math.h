@@ -377,32 +377,34 @@ JM_HD uint32_t jm_pack4_u8(float a, float b, float c, float d)
 // ---------------------------------------------------------------- colour, fast
 // Forward: the same decision as jm_fwd_colour (exact rational rounding, with
 // exact x.5 ties handed to the reference's double sequence), but the common
-// case runs on float fma/add only.  Y comes from a direct float chain (error
-// < 1e-4, ties are 1e-3 apart); Cb and Cr from exact integer-valued float
-// numerators (< 2^24) times 1e-4 (error < 2e-5, ties 1e-4 apart).  A value is a
-// tie candidate when its distance to the nearest integer exceeds the threshold;
-// `tie` collects the sign bits of (threshold - distance).
+// case runs on float fma/add only.
+//   Y      direct float chain (error < 1e-4; the rational values are 1e-3 apart).
+//   Cb, Cr centred chains  s = value - 128 + 5e-5  (error < 2e-5; the rational
+//          values are 1e-4 apart).  The bias makes the magic add round exact ties
+//          UP, which is what round() does unless the double sequence lands below
+//          the tie; c = rounded - 128 comes back as an exact float for the quad
+//          sums, and the byte (with the 256 -> 0 wrap of static_cast<uchar>,
+//          :67-70) sits in the low 8 bits of s + (MAGIC + 128).
+// A channel is an exact-tie candidate when its residual says "x.5": `t*` collect
+// that as a sign bit.
 struct JmFwdTies {
-    float sy, sb, sr; // the unrounded float values (Y, Cb, Cr)
+    float sy, sb, sr; // the unrounded float values (Y; Cb, Cr centred and biased)
     float ty, tb, tr; // sign bit set: that channel is an exact-tie candidate
 };
+#define JM_CHROMA_BIAS 5.0e-5f
 
 JM_HD void jm_fwd_colour_fast(float p0, float p1, float p2, float &uy, float &cb, float &cr, JmFwdTies &t)
 {
     t.sy = jm_fma(p2, 0.114f, jm_fma(p1, 0.587f, p0 * 0.299f));
     uy = t.sy + JM_MAGIC;
     float ry = t.sy - (uy - JM_MAGIC);
-    float nb = jm_fma(p2, 5000.0f, jm_fma(p1, -3313.0f, jm_fma(p0, -1687.0f, 1280000.0f)));
-    t.sb = nb * 1.0e-4f;
-    cb = (t.sb + JM_MAGIC) - JM_MAGIC;
-    float rb = t.sb - cb;
-    float nr = jm_fma(p2, -813.0f, jm_fma(p1, -4187.0f, jm_fma(p0, 5000.0f, 1280000.0f)));
-    t.sr = nr * 1.0e-4f;
-    cr = (t.sr + JM_MAGIC) - JM_MAGIC;
-    float rr = t.sr - cr;
     t.ty = 0.4995f - __builtin_fabsf(ry);
-    t.tb = 0.49995f - __builtin_fabsf(rb);
-    t.tr = 0.49995f - __builtin_fabsf(rr);
+    t.sb = jm_fma(p2, 0.5f, jm_fma(p1, -0.3313f, jm_fma(p0, -0.1687f, JM_CHROMA_BIAS)));
+    cb = (t.sb + JM_MAGIC) - JM_MAGIC;
+    t.tb = (t.sb - cb) + 0.4999f; // residual of a tie is -0.5 + bias
+    t.sr = jm_fma(p2, -0.0813f, jm_fma(p1, -0.4187f, jm_fma(p0, 0.5f, JM_CHROMA_BIAS)));
+    cr = (t.sr + JM_MAGIC) - JM_MAGIC;
+    t.tr = (t.sr - cr) + 0.4999f;
 }
 
 JM_HD bool jm_fwd_any_tie(const JmFwdTies &t)
@@ -410,10 +412,10 @@ JM_HD bool jm_fwd_any_tie(const JmFwdTies &t)
     return (int32_t)(jm_bits(t.ty) | jm_bits(t.tb) | jm_bits(t.tr)) < 0;
 }
 
-// Exact ties: the value is k + 0.5 as a rational (k = floor of the float value,
-// which is within 1e-4 of k + 0.5); the reference's double sequence
+// Exact ties: the value is k + 0.5 as a rational; the reference's double sequence
 // (encode_decode.cpp:58-63, one rounding per operation, no contraction) lands on,
-// above or below it, and round() goes up unless it is below.
+// above or below it, and round() goes up unless it is below.  cb/cr stay centred
+// (value - 128); 256 wraps to 0, i.e. -128 centred.
 JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, float &uy, float &cb, float &cr)
 {
     const double d0 = (double)p0, d1 = (double)p1, d2 = (double)p2;
@@ -428,24 +430,26 @@ JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, f
         double v = 128.0 + -0.1687 * d0;
         v = v + -0.3313 * d1;
         v = v + 0.5 * d2;
-        float k = ((t.sb - 0.5f) + JM_MAGIC) - JM_MAGIC;
-        cb = v >= (double)k + 0.5 ? k + 1.0f : k;
-        cb = cb == 256.0f ? 0.0f : cb; // static_cast<uchar>(256.0) wraps (:67-70)
+        float k = ((t.sb - 0.5f) + JM_MAGIC) - JM_MAGIC; // centred floor
+        cb = v >= (double)k + 128.5 ? k + 1.0f : k;
+        cb = cb == 128.0f ? -128.0f : cb;
     }
     if ((int32_t)jm_bits(t.tr) < 0) {
         double v = 128.0 + 0.5 * d0;
         v = v + -0.4187 * d1;
         v = v + -0.0813 * d2;
         float k = ((t.sr - 0.5f) + JM_MAGIC) - JM_MAGIC;
-        cr = v >= (double)k + 0.5 ? k + 1.0f : k;
-        cr = cr == 256.0f ? 0.0f : cr;
+        cr = v >= (double)k + 128.5 ? k + 1.0f : k;
+        cr = cr == 128.0f ? -128.0f : cr;
     }
 }
 
-// truncating mean of four chroma values (chromaSubsampling, :139-149) as MAGIC + mean
+// truncating mean of four chroma values (chromaSubsampling, :139-149) as MAGIC + mean;
+// `sum` is the sum of the four CENTRED values (each value - 128)
 JM_HD float jm_quad_mean_magic(float sum)
 {
-    return jm_fma(sum, 0.25f, -0.375f) + JM_MAGIC; // sum/4 is a multiple of 0.25: -0.375 makes nearest == floor
+    // sum/4 + 128 is a multiple of 0.25: -0.375 makes nearest == floor
+    return jm_fma(sum, 0.25f, 127.625f) + JM_MAGIC;
 }
 
 // low bytes of four magic floats -> one dword (a in byte 0)

@@ -44,8 +44,8 @@ void jmm_fwd_colour_fast(const uint8_t *src, size_t n, uint8_t *dst, long *n_can
             jm_fwd_colour_fix(p0, p1, p2, tie, uy, cb, cr);
         }
         dst[3 * i] = (uint8_t)(jm_bits(uy) & 0xFFu);
-        dst[3 * i + 1] = (uint8_t)(int)cb;
-        dst[3 * i + 2] = (uint8_t)(int)cr;
+        dst[3 * i + 1] = (uint8_t)((int)cb + 128); // centred; -128 is the wrapped 256
+        dst[3 * i + 2] = (uint8_t)((int)cr + 128);
     }
     *n_candidates = cand;
 }
@@ -146,8 +146,8 @@ const uint8_t *jmm_zigzag(void) { return kZigzag; }
 long jmm_check_quad_mean(void)
 {
     long bad = 0;
-    for (int s = 0; s <= 1020; ++s)
-        bad += (int)(jm_bits(jm_quad_mean_magic((float)s)) & 0xFFu) != s / 4;
+    for (int s = 0; s <= 1020; ++s) // the kernels sum centred values: s - 512
+        bad += (int)(jm_bits(jm_quad_mean_magic((float)(s - 512))) & 0xFFu) != s / 4;
     return bad;
 }
 
