@@ -112,6 +112,39 @@ int jpegamd_rle_encode_plane_dev(const int16_t *d_coef_zz, size_t nb, int32_t *d
 int jpegamd_rle_decode_plane_dev(const int32_t *d_pairs, size_t n_pairs, size_t nb, int16_t *d_coef_zz,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- entropy stage and .bin container (HOST, no GPU involved) --------------- */
+/* encodeChannel's tail + saveEncodedData, encode_decode.cpp:375-466, 648-658,
+ * 1093-1127, 1161-1217: three symbol streams (the (value, run) ints of the
+ * run-length stage, flattened) -> the bytes of a .bin file, bit-compatible with
+ * the reference built against libstdc++ (dictionary order and Huffman tie-breaks
+ * included).  *out_len receives the size needed; if out is NULL or cap is too
+ * small the call fails after setting it. */
+int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, size_t n_cb,
+                       const int32_t *sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
+                       uint8_t *out, size_t cap, size_t *out_len);
+/* loadEncodedData + decodeChannel's head, encode_decode.cpp:1225-1302, 660-668,
+ * 468-482: .bin bytes -> dims[6] (y, cb, cr rows/cols) and the three symbol
+ * streams.  Like the reference it decodes every bit of every payload byte, so
+ * up to 7 pad bits may yield spurious trailing symbols (the run-length decoder
+ * above drops them).  *n_* receive the symbol counts; if a buffer is too small
+ * the call fails after setting them. */
+int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
+                       int32_t *sym_y, size_t cap_y, size_t *n_y,
+                       int32_t *sym_cb, size_t cap_cb, size_t *n_cb,
+                       int32_t *sym_cr, size_t cap_cr, size_t *n_cr);
+
+/* ---- whole image, HOST buffers ------------------------------------------------ */
+/* main.cpp:96-133 with platform "GPU" (RGB2YCbCr, chromaSubsampling, mainEncode,
+ * saveEncodedData) : image -> malloc'ed .bin bytes (release with jpegamd_free). */
+int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
+                           const int32_t q_chroma[64], uint8_t **bin, size_t *bin_len);
+/* main.cpp:140-168 (loadEncodedData, mainDecode, upsampleChroma, YCbCr2RGB): .bin bytes
+ * -> image.  The tables are not stored in the file (the reference passes them
+ * again).  *rows, *cols are always set from the header; bgr == NULL only queries them. */
+int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_luma[64], const int32_t q_chroma[64],
+                             uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows, int *cols);
+void jpegamd_free(void *p);
+
 /* Times `iters` back-to-back launches of encode followed by decode on `stream`
  * with HIP events recorded on that same stream; writes the mean milliseconds
  * per launch of each kernel.  Used by bench.py for the roofline figures. */

@@ -34,6 +34,17 @@ SIGNATURES = {
                                      _c.c_size_t, _c.c_void_p],
     "jpegamd_rle_decode_plane_dev": [_c.c_void_p, _c.c_size_t, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                      _c.c_size_t, _c.c_void_p],
+    "jpegamd_bin_encode": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
+                           _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t,
+                           _c.POINTER(_c.c_size_t)],
+    "jpegamd_bin_decode": [_c.c_void_p, _c.c_size_t, _c.c_void_p,
+                           _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t),
+                           _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t),
+                           _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t)],
+    "jpegamd_compress_image": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                               _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)],
+    "jpegamd_decompress_image": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
+                                 _c.c_size_t, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)],
     "jpegamd_time_image_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                _c.POINTER(_c.c_float), _c.POINTER(_c.c_float)],
@@ -61,6 +72,8 @@ def load():
             fn.restype = _c.c_int
         lib.jpegamd_rle_workspace_bytes.argtypes = [_c.c_size_t]
         lib.jpegamd_rle_workspace_bytes.restype = _c.c_size_t
+        lib.jpegamd_free.argtypes = [_c.c_void_p]
+        lib.jpegamd_free.restype = None
         lib.jpegamd_last_error.argtypes = []
         lib.jpegamd_last_error.restype = _c.c_char_p
         _lib = lib

@@ -196,3 +196,64 @@ def rle_decode_plane(pairs, nb, stream=None):
     _lib.check(lib.jpegamd_rle_decode_plane_dev(src, n, int(nb), out.data_ptr(), work.data_ptr(),
                                                 work.numel(), _stream(stream)))
     return out
+
+
+def bin_encode(sym_y, sym_cb, sym_cr, y_rows, y_cols):
+    """Three (value, run) symbol streams (numpy int32, flattened) -> the bytes of the
+    reference's .bin container (jpegamd_bin_encode; host only, no GPU)."""
+    lib = _lib.load()
+    s = [np.ascontiguousarray(np.asarray(x).reshape(-1), dtype=np.int32) for x in (sym_y, sym_cb, sym_cr)]
+    need = ctypes.c_size_t(0)
+    args = [v for x in s for v in (x.ctypes.data, x.size)] + [int(y_rows), int(y_cols), int(y_rows) // 2, int(y_cols) // 2]
+    lib.jpegamd_bin_encode(*args, None, 0, ctypes.byref(need))  # sizing call
+    out = np.empty(need.value, np.uint8)
+    _lib.check(lib.jpegamd_bin_encode(*args, out.ctypes.data, out.size, ctypes.byref(need)))
+    return out[:need.value].tobytes()
+
+
+def bin_decode(data):
+    """.bin bytes -> (dims[6], [sym_y, sym_cb, sym_cr]) (jpegamd_bin_decode; host only)."""
+    lib = _lib.load()
+    buf = np.frombuffer(data, np.uint8)
+    dims = np.zeros(6, np.int32)
+    n = [ctypes.c_size_t(0) for _ in range(3)]
+    syms = [np.empty(0, np.int32) for _ in range(3)]
+    for _ in range(4):  # sizes are reported plane by plane
+        args = [v for x, c in zip(syms, n) for v in (x.ctypes.data, x.size, ctypes.byref(c))]
+        rc = lib.jpegamd_bin_decode(buf.ctypes.data, buf.size, dims.ctypes.data, *args)
+        if rc == 0:
+            return dims, [x[:c.value].copy() for x, c in zip(syms, n)]
+        if all(c.value <= x.size for x, c in zip(syms, n)):
+            _lib.check(rc)
+        syms = [np.empty(max(c.value, x.size), np.int32) for x, c in zip(syms, n)]
+    _lib.check(rc)
+
+
+def compress_image(bgr, q_luma, q_chroma):
+    """numpy uint8 [rows, cols, 3] on the HOST -> .bin bytes (jpegamd_compress_image)."""
+    lib = _lib.load()
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    ql, pl = _q(q_luma)
+    qc, pc = _q(q_chroma)
+    out, n = ctypes.c_void_p(), ctypes.c_size_t(0)
+    _lib.check(lib.jpegamd_compress_image(bgr.ctypes.data, bgr.shape[0], bgr.shape[1], bgr.shape[1] * 3, pl, pc,
+                                          ctypes.byref(out), ctypes.byref(n)))
+    try:
+        return ctypes.string_at(out, n.value)
+    finally:
+        lib.jpegamd_free(out)
+
+
+def decompress_image(data, q_luma, q_chroma):
+    """.bin bytes -> numpy uint8 [rows, cols, 3] on the HOST (jpegamd_decompress_image)."""
+    lib = _lib.load()
+    buf = np.frombuffer(data, np.uint8)
+    ql, pl = _q(q_luma)
+    qc, pc = _q(q_chroma)
+    r, c = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.jpegamd_decompress_image(buf.ctypes.data, buf.size, pl, pc, None, 0, 0,
+                                            ctypes.byref(r), ctypes.byref(c)))
+    out = np.empty((r.value, c.value, 3), np.uint8)
+    _lib.check(lib.jpegamd_decompress_image(buf.ctypes.data, buf.size, pl, pc, out.ctypes.data, out.size,
+                                            c.value * 3, ctypes.byref(r), ctypes.byref(c)))
+    return out

@@ -1,0 +1,299 @@
+// bin_container.cpp -- the reference's entropy stage and .bin container on the host,
+// bit-compatible with encode_decode.cpp:375-482 (frequency dictionary, Huffman
+// tree, codes, encode/decode) and :1093-1302 (bit packing, saveEncodedData,
+// loadEncodedData).  Part of libjpeg_amd.so.
+//
+// What makes a .bin reproducible is not the Huffman algorithm but two pieces of
+// libstdc++ behaviour the reference inherits:
+//   * the dictionary is a std::unordered_map<int,int> filled by freq[s]++ over the
+//     mixed (value, run) symbol stream (:375-383) and written in the container's
+//     iteration order (:1201-1217).  That order is a function of the sequence of
+//     *insertions* only, so a flat histogram plus the list of first occurrences,
+//     replayed into a real unordered_map, gives the same container;
+//   * equal frequencies leave the tree shape to std::priority_queue's sift order
+//     (:403-442: leaves pushed in (frequency, key) order, internal nodes compare
+//     by frequency alone).  The same adaptor with the same comparator and the same
+//     push/pop sequence is used here, over node indices instead of heap nodes.
+// Everything else is done differently from the reference for speed: no '0'/'1'
+// std::string (:458-466), codes live in flat tables indexed by symbol and bits are
+// packed MSB-first as they are produced (:1093-1127 give the byte layout).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <queue>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../../include/jpeg_amd.h"
+#include "../host_common.h"
+
+namespace {
+
+int fail(const char *text) { return jpegamd_fail("%s", text); }
+
+constexpr int kInternal = 99999; // the reference's marker for internal nodes (:424)
+
+struct Tree {
+    // node i: leaf (left < 0) carrying `value`, or internal with two children
+    std::vector<int> value, left, right;
+    std::vector<long long> freq;
+    int root = -1;
+    int add(int v, long long f, int l, int r)
+    {
+        value.push_back(v), freq.push_back(f), left.push_back(l), right.push_back(r);
+        return (int)value.size() - 1;
+    }
+    bool leaf(int n) const { return left[n] < 0; }
+};
+
+// build_huffman_tree (:403-442) from (key, frequency) pairs in container order
+void build_tree(const std::vector<std::pair<int, int>> &dict, Tree &t)
+{
+    std::vector<std::pair<int, int>> fv(dict);
+    std::sort(fv.begin(), fv.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+        return a.second != b.second ? a.second < b.second : a.first < b.first;
+    });
+    auto after = [&t](int a, int b) { return t.freq[a] > t.freq[b]; }; // Compare, :395-401
+    std::priority_queue<int, std::vector<int>, decltype(after)> heap(after);
+    for (const auto &p : fv)
+        heap.push(t.add(p.first, p.second, -1, -1));
+    while (heap.size() > 1) {
+        const int l = heap.top();
+        heap.pop();
+        const int r = heap.top();
+        heap.pop();
+        heap.push(t.add(kInternal, t.freq[l] + t.freq[r], l, r));
+    }
+    t.root = heap.empty() ? -1 : heap.top();
+}
+
+struct Code {
+    std::vector<uint8_t> bits; // one 0/1 per entry: codes can be longer than a machine word
+};
+
+// generate_huffman_codes (:444-456): left = 0, right = 1.  A key that were to equal
+// the internal marker would get no code there either; such input is rejected earlier.
+void assign_codes(const Tree &t, std::unordered_map<int, Code> &codes)
+{
+    if (t.root < 0)
+        return;
+    std::vector<std::pair<int, std::vector<uint8_t>>> stack;
+    stack.push_back({t.root, {}});
+    while (!stack.empty()) {
+        auto cur = std::move(stack.back());
+        stack.pop_back();
+        if (t.leaf(cur.first)) {
+            codes[t.value[cur.first]].bits = std::move(cur.second);
+            continue;
+        }
+        std::vector<uint8_t> l = cur.second, r = std::move(cur.second);
+        l.push_back(0), r.push_back(1);
+        stack.push_back({t.left[cur.first], std::move(l)});
+        stack.push_back({t.right[cur.first], std::move(r)});
+    }
+}
+
+struct BitWriter { // stringToBitstream's layout (:1093-1127): MSB first, last byte zero padded
+    std::vector<uint8_t> &out;
+    uint64_t acc = 0;
+    int n = 0;
+    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+    void put(uint64_t code, int len) // len <= 56
+    {
+        acc = (acc << len) | code;
+        n += len;
+        while (n >= 8) {
+            out.push_back((uint8_t)(acc >> (n - 8)));
+            n -= 8;
+        }
+    }
+    void finish()
+    {
+        if (n > 0)
+            out.push_back((uint8_t)(acc << (8 - n)));
+        n = 0;
+    }
+};
+
+struct Plane {
+    std::vector<std::pair<int, int>> dict; // (key, frequency) in unordered_map iteration order
+    std::vector<uint8_t> payload;
+};
+
+constexpr int kDense = 1 << 17; // symbols in [-65536, 65535] use flat tables
+
+int encode_plane(const int32_t *sym, size_t n, Plane &pl)
+{
+    // ---- frequency dictionary: counts + first-occurrence order ----------------
+    std::vector<int> count(kDense, 0);
+    std::unordered_map<int, int> sparse; // symbols outside the dense window (never from the kernels)
+    std::vector<int> order;
+    for (size_t i = 0; i < n; ++i) {
+        const int s = sym[i];
+        if (s == kInternal)
+            return fail("bin_encode: symbol 99999 collides with the reference's internal-node marker");
+        int &c = (s >= -kDense / 2 && s < kDense / 2) ? count[s + kDense / 2] : sparse[s];
+        if (c++ == 0)
+            order.push_back(s);
+    }
+    std::unordered_map<int, int> freq; // the reference's container, same insertion sequence
+    for (int s : order)
+        freq[s] = (s >= -kDense / 2 && s < kDense / 2) ? count[s + kDense / 2] : sparse[s];
+    pl.dict.assign(freq.begin(), freq.end());
+
+    // ---- tree and codes ---------------------------------------------------------
+    Tree t;
+    build_tree(pl.dict, t);
+    std::unordered_map<int, Code> codes;
+    assign_codes(t, codes);
+
+    // ---- payload ----------------------------------------------------------------
+    // flat (code, length) tables for the dense window when every code fits 56 bits
+    bool fast = sparse.empty();
+    for (const auto &kv : codes)
+        fast = fast && kv.second.bits.size() <= 56;
+    pl.payload.clear();
+    pl.payload.reserve(n / 2 + 16);
+    BitWriter w(pl.payload);
+    if (fast) {
+        std::vector<uint64_t> cbits(kDense, 0);
+        std::vector<uint8_t> clen(kDense, 0);
+        for (const auto &kv : codes) {
+            uint64_t v = 0;
+            for (uint8_t b : kv.second.bits)
+                v = (v << 1) | b;
+            cbits[kv.first + kDense / 2] = v;
+            clen[kv.first + kDense / 2] = (uint8_t)kv.second.bits.size();
+        }
+        for (size_t i = 0; i < n; ++i)
+            w.put(cbits[sym[i] + kDense / 2], clen[sym[i] + kDense / 2]);
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            for (uint8_t b : codes[sym[i]].bits)
+                w.put(b, 1);
+    }
+    w.finish();
+    if (pl.payload.size() > 0x7FFFFFFFu)
+        return fail("bin_encode: payload exceeds the container's int32 length field");
+    return 0;
+}
+
+void put_i32(uint8_t *&p, int v)
+{
+    std::memcpy(p, &v, 4); // file.write(reinterpret_cast<char*>(&int), 4): native little endian (:1162)
+    p += 4;
+}
+
+int get_i32(const uint8_t *p)
+{
+    int v;
+    std::memcpy(&v, p, 4);
+    return v;
+}
+
+} // namespace
+
+extern "C" {
+
+int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, size_t n_cb,
+                       const int32_t *sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
+                       uint8_t *out, size_t cap, size_t *out_len)
+{
+    if (!out_len || (!sym_y && n_y) || (!sym_cb && n_cb) || (!sym_cr && n_cr))
+        return fail("bin_encode: null pointer");
+    Plane pl[3];
+    if (encode_plane(sym_y, n_y, pl[0]) || encode_plane(sym_cb, n_cb, pl[1]) || encode_plane(sym_cr, n_cr, pl[2]))
+        return 1;
+    size_t need = 9 * 4 + 3 * 4;
+    for (const Plane &p : pl)
+        need += p.payload.size() + 8 * p.dict.size();
+    *out_len = need;
+    if (!out || cap < need)
+        return fail("bin_encode: output buffer too small (the size needed is in *out_len)");
+    uint8_t *w = out;
+    // saveEncodedData, :1161-1217
+    put_i32(w, y_rows), put_i32(w, y_cols);
+    put_i32(w, c_rows), put_i32(w, c_cols);
+    put_i32(w, c_rows), put_i32(w, c_cols);
+    for (const Plane &p : pl)
+        put_i32(w, (int)p.payload.size());
+    for (const Plane &p : pl) {
+        if (!p.payload.empty()) // (memcpy from an empty vector's null data() is undefined)
+            std::memcpy(w, p.payload.data(), p.payload.size());
+        w += p.payload.size();
+    }
+    for (const Plane &p : pl)
+        put_i32(w, (int)p.dict.size());
+    for (const Plane &p : pl)
+        for (const auto &kv : p.dict)
+            put_i32(w, kv.first), put_i32(w, kv.second);
+    return 0;
+}
+
+int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
+                       int32_t *sym_y, size_t cap_y, size_t *n_y,
+                       int32_t *sym_cb, size_t cap_cb, size_t *n_cb,
+                       int32_t *sym_cr, size_t cap_cr, size_t *n_cr)
+{
+    if (!bin || !dims || !n_y || !n_cb || !n_cr)
+        return fail("bin_decode: null pointer");
+    *n_y = *n_cb = *n_cr = 0;
+    // loadEncodedData, :1236-1296
+    if (len < 36)
+        return fail("bin_decode: shorter than the 9-int header");
+    for (int i = 0; i < 6; ++i)
+        dims[i] = get_i32(bin + 4 * i);
+    const int lens[3] = {get_i32(bin + 24), get_i32(bin + 28), get_i32(bin + 32)};
+    size_t off = 36;
+    const uint8_t *payload[3];
+    for (int c = 0; c < 3; ++c) {
+        if (lens[c] < 0 || (size_t)lens[c] > len - off)
+            return fail("bin_decode: payload length runs past the end of the file");
+        payload[c] = bin + off;
+        off += (size_t)lens[c];
+    }
+    if (len - off < 12)
+        return fail("bin_decode: dictionary sizes missing");
+    const int dsz[3] = {get_i32(bin + off), get_i32(bin + off + 4), get_i32(bin + off + 8)};
+    off += 12;
+    int32_t *outs[3] = {sym_y, sym_cb, sym_cr};
+    const size_t caps[3] = {cap_y, cap_cb, cap_cr};
+    size_t *ns[3] = {n_y, n_cb, n_cr};
+    for (int c = 0; c < 3; ++c) {
+        if (dsz[c] < 0 || (size_t)dsz[c] > (len - off) / 8)
+            return fail("bin_decode: dictionary runs past the end of the file");
+        std::unordered_map<int, int> freq; // :1279: insertion in file order
+        for (int i = 0; i < dsz[c]; ++i, off += 8)
+            freq[get_i32(bin + off)] = get_i32(bin + off + 4);
+        Tree t;
+        build_tree(std::vector<std::pair<int, int>>(freq.begin(), freq.end()), t); // decodeChannel, :664
+        size_t n = 0;
+        if (lens[c] > 0) {
+            if (t.root < 0 || t.leaf(t.root))
+                return fail("bin_decode: a plane with fewer than two distinct symbols has no decodable code "
+                            "(the reference dereferences a null child here, encode_decode.cpp:474)");
+            // bitstreamToString(len * 8) + huffman_decode (:1261-1263, :468-482): every bit of
+            // every byte, the zero padding included -- it may yield spurious trailing symbols
+            int cur = t.root;
+            for (int b = 0; b < lens[c]; ++b) {
+                const uint8_t byte = payload[c][b];
+                for (int i = 7; i >= 0; --i) {
+                    cur = ((byte >> i) & 1) ? t.right[cur] : t.left[cur];
+                    if (t.leaf(cur)) {
+                        if (n < caps[c] && outs[c])
+                            outs[c][n] = t.value[cur];
+                        ++n;
+                        cur = t.root;
+                    }
+                }
+            }
+        }
+        *ns[c] = n; // the count found; more than cap means the caller's buffer was too small
+        if (n > caps[c])
+            return fail("bin_decode: symbol buffer too small (the counts needed are in *n_y, *n_cb, *n_cr)");
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,160 @@
+// pipeline.cpp -- whole-image convenience entry points on HOST buffers: what the
+// reference's main.cpp does between cv::imread and the .bin file, and back
+// (main.cpp:96-168 with platform "GPU"): fused encode -> device run-length stage ->
+// host entropy coder -> .bin bytes, and the inverse.  Device memory is allocated
+// and freed per call, like the reference's kernel.cu:97-104 / 160-164.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/jpeg_amd.h"
+#include "../host_common.h"
+
+namespace {
+
+struct DevMem {
+    void *p = nullptr;
+    ~DevMem()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess ? 0 : 1; }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+// run-length pairs of one device coefficient plane, copied to the host
+int plane_symbols(const int16_t *d_coef, size_t nb, std::vector<int32_t> &sym)
+{
+    DevMem work, offs, pairs;
+    const size_t wbytes = jpegamd_rle_workspace_bytes(nb);
+    if (work.alloc(wbytes) || offs.alloc((nb + 1) * sizeof(uint32_t)))
+        return jpegamd_fail("compress_image: out of device memory");
+    size_t cap = nb * 16 < nb * 64 ? nb * 16 : nb * 64; // a typical plane needs far fewer than 64 pairs per block
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (pairs.p) {
+            (void)hipFree(pairs.p);
+            pairs.p = nullptr;
+        }
+        if (pairs.alloc(cap * 8))
+            return jpegamd_fail("compress_image: out of device memory");
+        if (jpegamd_rle_encode_plane_dev(d_coef, nb, pairs.as<int32_t>(), cap, offs.as<uint32_t>(), work.p, wbytes,
+                                         nullptr))
+            return 1;
+        uint32_t total = 0;
+        JPEGAMD_HIPCHK(hipMemcpy(&total, offs.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost));
+        if (total <= cap) {
+            sym.resize((size_t)total * 2);
+            if (total)
+                JPEGAMD_HIPCHK(hipMemcpy(sym.data(), pairs.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+            return 0;
+        }
+        cap = total;
+    }
+    return jpegamd_fail("compress_image: run-length pass did not converge");
+}
+
+} // namespace
+
+extern "C" {
+
+void jpegamd_free(void *p) { std::free(p); }
+
+int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
+                           const int32_t q_chroma[64], uint8_t **bin, size_t *bin_len)
+{
+    if (!bgr || !bin || !bin_len)
+        return jpegamd_fail("compress_image: null pointer");
+    if (rows <= 0 || cols <= 0 || (rows & 15) || (cols & 15) || stride < (size_t)cols * 3)
+        return jpegamd_fail("compress_image: rows=%d cols=%d must be positive multiples of 16 and stride >= 3*cols "
+                            "(the reference resizes first, encode_decode.cpp:29-37)", rows, cols);
+    const size_t nby = (size_t)(rows / 8) * (cols / 8), nbc = (size_t)(rows / 16) * (cols / 16);
+    DevMem d_bgr, d_y, d_cb, d_cr;
+    if (d_bgr.alloc((size_t)rows * cols * 3) || d_y.alloc(nby * 128) || d_cb.alloc(nbc * 128) || d_cr.alloc(nbc * 128))
+        return jpegamd_fail("compress_image: out of device memory");
+    JPEGAMD_HIPCHK(hipMemcpy2D(d_bgr.p, (size_t)cols * 3, bgr, stride, (size_t)cols * 3, rows, hipMemcpyHostToDevice));
+    if (jpegamd_encode_image_dev(d_bgr.as<uint8_t>(), rows, cols, (size_t)cols * 3, q_luma, q_chroma,
+                                 d_y.as<int16_t>(), d_cb.as<int16_t>(), d_cr.as<int16_t>(), nullptr))
+        return 1;
+    std::vector<int32_t> sy, scb, scr;
+    if (plane_symbols(d_y.as<int16_t>(), nby, sy) || plane_symbols(d_cb.as<int16_t>(), nbc, scb) ||
+        plane_symbols(d_cr.as<int16_t>(), nbc, scr))
+        return 1;
+    size_t need = 0;
+    (void)jpegamd_bin_encode(sy.data(), sy.size(), scb.data(), scb.size(), scr.data(), scr.size(), rows, cols,
+                             rows / 2, cols / 2, nullptr, 0, &need); // sizing call
+    uint8_t *buf = static_cast<uint8_t *>(std::malloc(need ? need : 1));
+    if (!buf)
+        return jpegamd_fail("compress_image: out of host memory");
+    if (jpegamd_bin_encode(sy.data(), sy.size(), scb.data(), scb.size(), scr.data(), scr.size(), rows, cols,
+                           rows / 2, cols / 2, buf, need, &need)) {
+        std::free(buf);
+        return 1;
+    }
+    *bin = buf;
+    *bin_len = need;
+    return 0;
+}
+
+int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_luma[64], const int32_t q_chroma[64],
+                             uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows, int *cols)
+{
+    if (!bin || !rows || !cols)
+        return jpegamd_fail("decompress_image: null pointer");
+    int32_t dims[6];
+    size_t n[3] = {0, 0, 0};
+    // counting pass (no buffers), then the real one
+    int rc = jpegamd_bin_decode(bin, len, dims, nullptr, 0, &n[0], nullptr, 0, &n[1], nullptr, 0, &n[2]);
+    if (rc && n[0] == 0 && n[1] == 0 && n[2] == 0)
+        return 1; // malformed container (a too-small buffer is expected here and reports counts)
+    // the counting pass stops at the first plane that overflows its (zero) capacity: walk plane by plane
+    std::vector<int32_t> sym[3];
+    for (int pass = 0; pass < 4; ++pass) {
+        for (int c = 0; c < 3; ++c)
+            sym[c].resize(n[c]);
+        rc = jpegamd_bin_decode(bin, len, dims, sym[0].data(), sym[0].size(), &n[0], sym[1].data(), sym[1].size(),
+                                &n[1], sym[2].data(), sym[2].size(), &n[2]);
+        if (!rc)
+            break;
+        if (n[0] <= sym[0].size() && n[1] <= sym[1].size() && n[2] <= sym[2].size())
+            return 1; // failed for another reason
+    }
+    if (rc)
+        return 1;
+    const int r = dims[0], c = dims[1];
+    *rows = r, *cols = c;
+    if (r <= 0 || c <= 0 || (r & 15) || (c & 15) || dims[2] != r / 2 || dims[3] != c / 2 || dims[4] != r / 2 ||
+        dims[5] != c / 2)
+        return jpegamd_fail("decompress_image: header %dx%d / %dx%d / %dx%d is not a 4:2:0 image with sides that "
+                            "are multiples of 16", dims[0], dims[1], dims[2], dims[3], dims[4], dims[5]);
+    if (!bgr)
+        return 0; // size query
+    if (stride < (size_t)c * 3 || cap_bytes < (size_t)(r - 1) * stride + (size_t)c * 3)
+        return jpegamd_fail("decompress_image: output buffer too small for %dx%d", r, c);
+    const size_t nb[3] = {(size_t)(r / 8) * (c / 8), (size_t)(r / 16) * (c / 16), (size_t)(r / 16) * (c / 16)};
+    DevMem d_coef[3], d_out;
+    for (int k = 0; k < 3; ++k) {
+        DevMem d_pairs, work;
+        const size_t np = sym[k].size() / 2; // an odd trailing symbol has no run: dropped
+        const size_t use = np < nb[k] * 64 + 8 ? np : nb[k] * 64 + 8; // pairs beyond that cannot reach the plane
+        const size_t wbytes = jpegamd_rle_workspace_bytes(nb[k]);
+        if (d_coef[k].alloc(nb[k] * 128) || d_pairs.alloc(use * 8) || work.alloc(wbytes))
+            return jpegamd_fail("decompress_image: out of device memory");
+        if (use)
+            JPEGAMD_HIPCHK(hipMemcpy(d_pairs.p, sym[k].data(), use * 8, hipMemcpyHostToDevice));
+        if (jpegamd_rle_decode_plane_dev(d_pairs.as<int32_t>(), use, nb[k], d_coef[k].as<int16_t>(), work.p, wbytes,
+                                         nullptr))
+            return 1;
+        JPEGAMD_HIPCHK(hipDeviceSynchronize()); // d_pairs and work are freed at the end of this iteration
+    }
+    if (d_out.alloc((size_t)r * c * 3))
+        return jpegamd_fail("decompress_image: out of device memory");
+    if (jpegamd_decode_image_dev(d_coef[0].as<int16_t>(), d_coef[1].as<int16_t>(), d_coef[2].as<int16_t>(), r, c,
+                                 q_luma, q_chroma, d_out.as<uint8_t>(), (size_t)c * 3, nullptr))
+        return 1;
+    JPEGAMD_HIPCHK(hipMemcpy2D(bgr, stride, d_out.p, (size_t)c * 3, (size_t)c * 3, r, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+} // extern "C"
