@@ -95,24 +95,31 @@ void assign_codes(const Tree &t, std::unordered_map<int, Code> &codes)
 }
 
 struct BitWriter { // stringToBitstream's layout (:1093-1127): MSB first, last byte zero padded
-    std::vector<uint8_t> &out;
+    uint8_t *p;
     uint64_t acc = 0;
     int n = 0;
-    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
-    void put(uint64_t code, int len) // len <= 56
+    explicit BitWriter(uint8_t *dst) : p(dst) {}
+    void put(uint64_t code, int len) // len <= 32 per call; the caller sized the buffer
     {
         acc = (acc << len) | code;
         n += len;
-        while (n >= 8) {
-            out.push_back((uint8_t)(acc >> (n - 8)));
-            n -= 8;
+        if (n >= 32) {
+            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> (n - 32)));
+            std::memcpy(p, &w, 4);
+            p += 4;
+            n -= 32;
         }
     }
-    void finish()
+    uint8_t *finish()
     {
+        while (n >= 8) {
+            *p++ = (uint8_t)(acc >> (n - 8));
+            n -= 8;
+        }
         if (n > 0)
-            out.push_back((uint8_t)(acc << (8 - n)));
+            *p++ = (uint8_t)(acc << (8 - n));
         n = 0;
+        return p;
     }
 };
 
@@ -149,31 +156,42 @@ int encode_plane(const int32_t *sym, size_t n, Plane &pl)
     assign_codes(t, codes);
 
     // ---- payload ----------------------------------------------------------------
-    // flat (code, length) tables for the dense window when every code fits 56 bits
+    // flat (code, length) tables for the dense window when every code fits 32 bits
     bool fast = sparse.empty();
-    for (const auto &kv : codes)
-        fast = fast && kv.second.bits.size() <= 56;
-    pl.payload.clear();
-    pl.payload.reserve(n / 2 + 16);
-    BitWriter w(pl.payload);
+    size_t longest = 0;
+    for (const auto &kv : codes) {
+        fast = fast && kv.second.bits.size() <= 32;
+        longest = std::max(longest, kv.second.bits.size());
+    }
     if (fast) {
-        std::vector<uint64_t> cbits(kDense, 0);
+        std::vector<uint32_t> cbits(kDense, 0);
         std::vector<uint8_t> clen(kDense, 0);
+        unsigned long long total_bits = 0;
         for (const auto &kv : codes) {
-            uint64_t v = 0;
+            uint32_t v = 0;
             for (uint8_t b : kv.second.bits)
                 v = (v << 1) | b;
             cbits[kv.first + kDense / 2] = v;
             clen[kv.first + kDense / 2] = (uint8_t)kv.second.bits.size();
+            total_bits += (unsigned long long)kv.second.bits.size() * (unsigned long long)freq[kv.first];
         }
+        pl.payload.resize((size_t)((total_bits + 7) / 8) + 8);
+        BitWriter w(pl.payload.data());
         for (size_t i = 0; i < n; ++i)
             w.put(cbits[sym[i] + kDense / 2], clen[sym[i] + kDense / 2]);
+        pl.payload.resize((size_t)(w.finish() - pl.payload.data()));
     } else {
+        unsigned long long total_bits = 0;
+        for (const auto &kv : codes)
+            total_bits += (unsigned long long)kv.second.bits.size() * (unsigned long long)freq[kv.first];
+        pl.payload.resize((size_t)((total_bits + 7) / 8) + 8);
+        BitWriter w(pl.payload.data());
         for (size_t i = 0; i < n; ++i)
             for (uint8_t b : codes[sym[i]].bits)
                 w.put(b, 1);
+        pl.payload.resize((size_t)(w.finish() - pl.payload.data()));
     }
-    w.finish();
+    (void)longest;
     if (pl.payload.size() > 0x7FFFFFFFu)
         return fail("bin_encode: payload exceeds the container's int32 length field");
     return 0;
@@ -274,19 +292,41 @@ int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
                 return fail("bin_decode: a plane with fewer than two distinct symbols has no decodable code "
                             "(the reference dereferences a null child here, encode_decode.cpp:474)");
             // bitstreamToString(len * 8) + huffman_decode (:1261-1263, :468-482): every bit of
-            // every byte, the zero padding included -- it may yield spurious trailing symbols
-            int cur = t.root;
-            for (int b = 0; b < lens[c]; ++b) {
-                const uint8_t byte = payload[c][b];
-                for (int i = 7; i >= 0; --i) {
-                    cur = ((byte >> i) & 1) ? t.right[cur] : t.left[cur];
-                    if (t.leaf(cur)) {
-                        if (n < caps[c] && outs[c])
-                            outs[c][n] = t.value[cur];
-                        ++n;
-                        cur = t.root;
-                    }
+            // every byte, the zero padding included -- it may yield spurious trailing symbols.
+            // A 12-bit window resolves short codes in one step; longer ones continue bit by bit
+            // from the node the window reaches, so the symbol sequence is the bit-serial walk's.
+            constexpr int kWin = 12;
+            std::vector<int> win_node(1 << kWin), win_used(1 << kWin);
+            for (int v = 0; v < (1 << kWin); ++v) {
+                int cur = t.root, used = 0;
+                while (used < kWin && !t.leaf(cur)) {
+                    cur = ((v >> (kWin - 1 - used)) & 1) ? t.right[cur] : t.left[cur];
+                    ++used;
                 }
+                win_node[v] = cur, win_used[v] = used;
+            }
+            const unsigned long long nbits = (unsigned long long)lens[c] * 8;
+            auto bit_at = [&](unsigned long long i) { return (payload[c][i >> 3] >> (7 - (i & 7))) & 1; };
+            unsigned long long pos = 0;
+            while (pos < nbits) {
+                int cur;
+                if (pos + 64 <= nbits) { // a whole window (and then some) is available
+                    uint64_t w;
+                    std::memcpy(&w, payload[c] + (pos >> 3), 8);
+                    w = __builtin_bswap64(w) << (pos & 7);
+                    const int v = (int)(w >> (64 - kWin));
+                    cur = win_node[v];
+                    pos += win_used[v];
+                } else {
+                    cur = t.root;
+                }
+                while (!t.leaf(cur) && pos < nbits)
+                    cur = bit_at(pos++) ? t.right[cur] : t.left[cur];
+                if (!t.leaf(cur))
+                    break; // ran out of bits inside a code: the reference emits nothing for it either
+                if (n < caps[c] && outs[c])
+                    outs[c][n] = t.value[cur];
+                ++n;
             }
         }
         *ns[c] = n; // the count found; more than cap means the caller's buffer was too small

@@ -103,25 +103,9 @@ int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_lum
     if (!bin || !rows || !cols)
         return jpegamd_fail("decompress_image: null pointer");
     int32_t dims[6];
-    size_t n[3] = {0, 0, 0};
-    // counting pass (no buffers), then the real one
-    int rc = jpegamd_bin_decode(bin, len, dims, nullptr, 0, &n[0], nullptr, 0, &n[1], nullptr, 0, &n[2]);
-    if (rc && n[0] == 0 && n[1] == 0 && n[2] == 0)
-        return 1; // malformed container (a too-small buffer is expected here and reports counts)
-    // the counting pass stops at the first plane that overflows its (zero) capacity: walk plane by plane
-    std::vector<int32_t> sym[3];
-    for (int pass = 0; pass < 4; ++pass) {
-        for (int c = 0; c < 3; ++c)
-            sym[c].resize(n[c]);
-        rc = jpegamd_bin_decode(bin, len, dims, sym[0].data(), sym[0].size(), &n[0], sym[1].data(), sym[1].size(),
-                                &n[1], sym[2].data(), sym[2].size(), &n[2]);
-        if (!rc)
-            break;
-        if (n[0] <= sym[0].size() && n[1] <= sym[1].size() && n[2] <= sym[2].size())
-            return 1; // failed for another reason
-    }
-    if (rc)
-        return 1;
+    if (len < 36)
+        return jpegamd_fail("decompress_image: shorter than the 9-int header");
+    std::memcpy(dims, bin, 24);
     const int r = dims[0], c = dims[1];
     *rows = r, *cols = c;
     if (r <= 0 || c <= 0 || (r & 15) || (c & 15) || dims[2] != r / 2 || dims[3] != c / 2 || dims[4] != r / 2 ||
@@ -133,6 +117,31 @@ int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_lum
     if (stride < (size_t)c * 3 || cap_bytes < (size_t)(r - 1) * stride + (size_t)c * 3)
         return jpegamd_fail("decompress_image: output buffer too small for %dx%d", r, c);
     const size_t nb[3] = {(size_t)(r / 8) * (c / 8), (size_t)(r / 16) * (c / 16), (size_t)(r / 16) * (c / 16)};
+    // A plane of nb blocks has at most 64 pairs per block (plus what up to 7 pad bits decode
+    // to), and no more symbols than payload bits.  Buffers are left uninitialised on purpose.
+    struct HostBuf {
+        int32_t *p = nullptr;
+        size_t size() const { return n; }
+        size_t n = 0;
+        ~HostBuf() { std::free(p); }
+    } sym[3];
+    size_t n[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        int32_t plen;
+        std::memcpy(&plen, bin + 24 + 4 * k, 4);
+        size_t cap = nb[k] * 128 + 16;
+        if (plen >= 0 && (size_t)plen * 8 < cap)
+            cap = (size_t)plen * 8;
+        sym[k].p = static_cast<int32_t *>(std::malloc((cap ? cap : 1) * sizeof(int32_t)));
+        if (!sym[k].p)
+            return jpegamd_fail("decompress_image: out of host memory");
+        sym[k].n = cap;
+    }
+    if (jpegamd_bin_decode(bin, len, dims, sym[0].p, sym[0].n, &n[0], sym[1].p, sym[1].n, &n[1], sym[2].p, sym[2].n,
+                           &n[2]))
+        return 1; // includes "more symbols than the plane sizes in the header allow"
+    for (int k = 0; k < 3; ++k)
+        sym[k].n = n[k];
     DevMem d_coef[3], d_out;
     for (int k = 0; k < 3; ++k) {
         DevMem d_pairs, work;
@@ -142,7 +151,7 @@ int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_lum
         if (d_coef[k].alloc(nb[k] * 128) || d_pairs.alloc(use * 8) || work.alloc(wbytes))
             return jpegamd_fail("decompress_image: out of device memory");
         if (use)
-            JPEGAMD_HIPCHK(hipMemcpy(d_pairs.p, sym[k].data(), use * 8, hipMemcpyHostToDevice));
+            JPEGAMD_HIPCHK(hipMemcpy(d_pairs.p, sym[k].p, use * 8, hipMemcpyHostToDevice));
         if (jpegamd_rle_decode_plane_dev(d_pairs.as<int32_t>(), use, nb[k], d_coef[k].as<int16_t>(), work.p, wbytes,
                                          nullptr))
             return 1;
