@@ -19,6 +19,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/jpeg_amd.h"
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
         qtab[threadIdx.x] = qp.t[threadIdx.x >> 6].inv100q[threadIdx.x & 63];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
     const int tile = blockIdx.x * kWavesPerWg + wave;
     if (tile >= n_tiles)
         return; // whole wave leaves together; nothing else is shared between waves
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
         qtab[threadIdx.x] = qp.t[threadIdx.x >> 6].q[threadIdx.x & 63];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
     const int tile = blockIdx.x * kWavesPerWg + wave;
     if (tile >= n_tiles)
         return;
@@ -409,6 +410,239 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     }
 }
 
+// =============================================================================
+// Fused kernels with the 8x8 transforms on the matrix cores.
+//
+// Same tile as above (one wave = 512 x 16 pixels), but the DCT runs as
+// v_mfma_f32_16x16x4_f32 products over groups of 16 pixel columns x 16 rows
+// (= 2 x 2 luma blocks, or 2 chroma blocks of Cb and of Cr), which leaves the VALU
+// for colour conversion and quantisation only.  Per group, with g = lane >> 4 and
+// xl = lane & 15:
+//   pass one   D1[x][(s,u)]       = sum_(s',y) P[(s',y)][x]   * [s'=s]   m(u,y)     (4 MFMAs, K = 16)
+//   pass two   D2[(s,u)][(b,v)]   = sum_x      D1[x][(s,u)]   * [x/8=b]  100 m(v,x%8) (4 MFMAs)
+// s = block row (or chroma plane), b = block column.  D1's accumulator register r
+// of lane l holds x = 4g + r for (s,u) = xl -- exactly the A-operand layout of
+// K-step r of pass two once the constant B operand is permuted the same way -- so
+// nothing moves between the passes.  Lane l ends up with the four coefficients
+// (s,u) = 4g + r, (b,v) = xl of its group: quantised and stored as int16 straight
+// to their zigzag slots.  The level shift is the accumulator's initial value.
+// Numerics: an MFMA is a k-ordered fma chain, replayed on the host by
+// jm_mfma_fdct_block / jm_mfma_idct_block.
+// =============================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kYBytes = 16 * 512;                  // 16 luma rows of the tile
+constexpr int kWaveLdsM = kYBytes + kChromaBytes;   // 12288
+
+// natural (row-major) index -> zigzag scan position: the inverse of kZZ
+__device__ constexpr uint8_t kZZInv[64] = {
+    0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42,
+    3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+    10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+    21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+// Sample (k, X) of a 16-row operand image, k = contraction index (luma: tile row;
+// chroma: 8*plane + row), stored so that lane (g, xl) of group c finds its four
+// K-steps k = 4t + g in one dword:  [X >> 4][k & 3][X & 15][k >> 2].
+__device__ __forceinline__ int operand_byte(int k, int X)
+{
+    return (((X >> 4) * 4 + (k & 3)) * 16 + (X & 15)) * 4 + (k >> 2);
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// NG groups at once: operand dwords (four bytes = K-steps) -> four quantised coefficients
+// (magic floats) per group.  The groups' MFMA chains are interleaved so that every
+// accumulator is revisited only after NG - 1 independent products (a dependent
+// 16x16x4 needs 40 cycles, the pipe accepts one every 32).
+template <int NG>
+__device__ __forceinline__ void groups_fdct_quant(const uint32_t (&a4)[NG], const float (&b1)[4],
+                                                  const float (&b2)[4], f32x4 c1, const float (&qm)[4],
+                                                  float (&q)[NG][4])
+{
+    f32x4 d1[NG], d2[NG];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+            d1[i] = mfma4((float)((a4[i] >> (8 * t)) & 0xFFu), b1[t], t == 0 ? c1 : d1[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+            d2[i] = mfma4(d1[i][r], b2[r], r == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : d2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = (d2[i][r] + JM_MAGIC) - JM_MAGIC; // round(100 c), :284
+            q[i][r] = jm_fma(x, qm[r], JM_MAGIC);       // roundf(c / Q), :306 (see jm_quantise_block)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void encode_image_mfma_kernel(
+    const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
+    int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
+    int tiles_x, int n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kWaveLdsM];
+    __shared__ __attribute__((aligned(16))) float qtab[128];
+    if (threadIdx.x < 128)
+        qtab[threadIdx.x] = qp.t[threadIdx.x >> 6].inv100q[threadIdx.x & 63];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
+    const int tile = blockIdx.x * kWavesPerWg + wave;
+    if (tile >= n_tiles)
+        return; // whole wave leaves together; nothing else is shared between waves
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    uint8_t *ybuf = lds + wave * kWaveLdsM; // luma operand image, 16 rows x 512
+    uint8_t *cbuf = ybuf + kYBytes;         // chroma operand image, (Cb, Cr) x 8 rows x 256
+    const int x0 = tx * kWaveTileW;
+    const int bw_y = cols >> 3, bw_c = cols >> 4;
+
+    // ---- colour + 4:2:0 for the 16 tile rows (same task scheme as encode_image_kernel) ----
+    auto task_load = [&](int T, U3 &a, U3 &b) {
+        const int t = T & 7;
+        const int row = ty * 16 + (T >> 3) * 8 + 2 * (t >> 1);
+        const int x = x0 + 4 * (lane + 64 * (t & 1));
+        if (x < cols) {
+            const uint8_t *p = bgr + (size_t)row * stride + (size_t)x * 3;
+            a = *reinterpret_cast<const U3 *>(p);
+            b = *reinterpret_cast<const U3 *>(p + stride);
+        }
+    };
+    U3 cur_a = {0, 0, 0}, cur_b = {0, 0, 0}, nxt_a = {0, 0, 0}, nxt_b = {0, 0, 0};
+    task_load(0, cur_a, cur_b);
+    task_load(1, nxt_a, nxt_b);
+#pragma unroll 1
+    for (int T = 0; T < 16; ++T) {
+        U3 far_a = {0, 0, 0}, far_b = {0, 0, 0};
+        if (T + 2 < 16)
+            task_load(T + 2, far_a, far_b);
+        const int it = T >> 3, rp = (T & 7) >> 1;
+        const int G = lane + 64 * (T & 1); // pixel group: columns 4G .. 4G+3 of the tile
+        if (x0 + 4 * G < cols) {
+            float ya[4], yb[4], sum_b[2] = {0.f, 0.f}, sum_r[2] = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int row = 0; row < 2; ++row) {
+                    const U3 &px = row ? cur_b : cur_a;
+                    float uy, cb, cr;
+                    JmFwdTies tie;
+                    const float p0 = (float)u3_byte(px, 3 * j), p1 = (float)u3_byte(px, 3 * j + 1),
+                                p2 = (float)u3_byte(px, 3 * j + 2);
+                    jm_fwd_colour_fast(p0, p1, p2, uy, cb, cr, tie);
+                    if (__builtin_expect(jm_fwd_any_tie(tie), 0)) // an exact x.5 somewhere: ask the doubles
+                        jm_fwd_colour_fix(p0, p1, p2, tie, uy, cb, cr);
+                    (row ? yb : ya)[j] = uy;
+                    sum_b[j >> 1] += cb;
+                    sum_r[j >> 1] += cr;
+                }
+            }
+            // luma bytes (the low byte of each magic float) into the operand image
+            const int R0 = 8 * it + 2 * rp;
+            uint8_t *yp = ybuf + operand_byte(0, 4 * G); // + (R & 3) * 64 + (R >> 2) + 4 j
+            const int o0 = (R0 & 3) * 64 + (R0 >> 2), o1 = ((R0 + 1) & 3) * 64 + ((R0 + 1) >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                yp[o0 + 4 * j] = (uint8_t)jm_bits(ya[j]);
+                yp[o1 + 4 * j] = (uint8_t)jm_bits(yb[j]);
+            }
+            // chromaSubsampling: truncating mean of the quad (:139-149); chroma row 4 it + rp
+            const int kc = 4 * it + rp; // contraction index of Cb; Cr is kc + 8
+            uint8_t *cp = cbuf + operand_byte(0, 2 * G);
+            const int ob = (kc & 3) * 64 + (kc >> 2), orr = ob + 2; // (kc + 8) >> 2 = (kc >> 2) + 2
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                cp[ob + 4 * jj] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[jj]));
+                cp[orr + 4 * jj] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_r[jj]));
+            }
+        }
+        cur_a = nxt_a, cur_b = nxt_b;
+        nxt_a = far_a, nxt_b = far_b;
+    }
+    wave_lds_fence();
+
+    // ---- transforms on the matrix cores ------------------------------------------------
+    const int g = lane >> 4, xl = lane & 15;
+    float b1[4], b2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = 4 * t + g; // pass one: k = (s', y), column xl = (s, u)
+        b1[t] = (k >> 3) == (xl >> 3) ? jm_dct_basis(xl & 7, k & 7, 1.0) : 0.0f;
+        const int x = 4 * g + t; // pass two, K-step t: x = 4g + t, column xl = (b, v)
+        b2[t] = (x >> 3) == (xl >> 3) ? jm_dct_basis(xl & 7, x & 7, 100.0) : 0.0f;
+    }
+    const float lv = (xl & 7) == 0 ? JM_LEVEL_DC : 0.0f; // recenterAroundZero (:289-298) reaches u = 0 only
+    const f32x4 c1 = {lv, lv, lv, lv};
+    // this lane's four outputs of a group: (s, u) = 4g + r, (b, v) = xl
+    float qml[4], qmc[4];
+    int zz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int nat = (4 * (g & 1) + r) * 8 + (xl & 7);
+        qml[r] = qtab[nat];
+        qmc[r] = qtab[64 + nat];
+        zz[r] = kZZInv[nat];
+    }
+    constexpr int NG = 4; // groups in flight
+    {
+        // luma: 2 x 2 blocks per group; strip s = g >> 1, block column 2c + (xl >> 3)
+        const int n_groups = min(32, (cols - x0) >> 4);
+        int16_t *dst = coef_y + ((size_t)(ty * 2 + (g >> 1)) * bw_y + tx * 64 + (xl >> 3)) * 64;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(ybuf) + g * 16 + xl;
+#pragma unroll 1
+        for (int c0 = 0; c0 < n_groups; c0 += NG) {
+            uint32_t a4[NG];
+            float q[NG][4];
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                a4[i] = src[(c0 + i) * 64]; // groups beyond n_groups read stale LDS: finite bytes, never stored
+            groups_fdct_quant<NG>(a4, b1, b2, c1, qml, q);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                if (c0 + i < n_groups) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(c0 + i) * 128 + zz[r]] = (int16_t)(jm_bits(q[i][r]) & 0xFFFFu);
+                }
+            }
+        }
+    }
+    {
+        // chroma: plane p = g >> 1 (Cb, Cr), 2 blocks per group
+        const int n_blocks = min(32, bw_c - tx * 32);
+        const int n_groups = (n_blocks + 1) >> 1;
+        int16_t *dst = ((g >> 1) ? coef_cr : coef_cb) + ((size_t)ty * bw_c + tx * 32 + (xl >> 3)) * 64;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(cbuf) + g * 16 + xl;
+#pragma unroll 1
+        for (int c0 = 0; c0 < n_groups; c0 += NG) {
+            uint32_t a4[NG];
+            float q[NG][4];
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                a4[i] = src[(c0 + i) * 64];
+            groups_fdct_quant<NG>(a4, b1, b2, c1, qmc, q);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                if (2 * (c0 + i) + (xl >> 3) < n_blocks) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(c0 + i) * 128 + zz[r]] = (int16_t)(jm_bits(q[i][r]) & 0xFFFFu);
+                }
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------- plane level
 // lane = block, wave = 64 consecutive blocks of one block-row.  Any rows/cols:
 // samples outside the plane read as 0 before the level shift (extractBlocks,
@@ -419,7 +653,7 @@ __global__ __launch_bounds__(256) void encode_plane_kernel(
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kStageBytes];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
     const int grp = blockIdx.x * kWavesPerWg + wave;
     if (grp >= n_groups)
         return;
@@ -473,7 +707,7 @@ __global__ __launch_bounds__(256) void decode_plane_kernel(
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kStageBytes];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
     const int grp = blockIdx.x * kWavesPerWg + wave;
     if (grp >= n_groups)
         return;
@@ -590,6 +824,15 @@ int check_image(const void *p, int rows, int cols, size_t stride, const char *wh
     return 0;
 }
 
+// JPEGAMD_TRANSFORM=mfma runs the forward transform of the fused encoder on the matrix
+// cores (encode_image_mfma_kernel).  Measured slower than the VALU kernel on gfx950
+// (DESIGN.md 3): f32 MFMA does not overlap with VALU work there.  Read on every call.
+bool use_matrix_cores()
+{
+    const char *e = getenv("JPEGAMD_TRANSFORM");
+    return e && strcmp(e, "mfma") == 0;
+}
+
 struct DevBuf { // host-pointer entry points: per-call device memory
     void *p = nullptr;
     ~DevBuf()
@@ -648,8 +891,12 @@ int jpegamd_encode_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t st
     const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
     const int n_tiles = tiles_x * (rows / 16);
     const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
-    hipLaunchKernelGGL(encode_image_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
-                       d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
+    if (use_matrix_cores())
+        hipLaunchKernelGGL(encode_image_mfma_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
+                           d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
+    else
+        hipLaunchKernelGGL(encode_image_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
+                           d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -234,6 +234,81 @@ JM_HD void jm_idct8(float &x0, float &x1, float &x2, float &x3,
     x4 = e3 - o3;
 }
 
+// ------------------------------------------------- 8x8 DCT on the matrix cores
+// v_mfma_f32_16x16x4_f32 accumulates D = fma(a_k, b_k, ...fma(a_0, b_0, C)) in k order
+// with one f32 rounding per product (cdna_hip_programming.md, FP32-input MFMA), so the
+// kernels' matrix-core transform is a plain fma chain the host can replay bit for bit.
+// The basis  m(u, n) = (c_u / 2) cos((2n+1) u pi / 16)  is rounded to float once.
+JM_HD float jm_dct_basis(int u, int n, double scale)
+{
+    // (2n+1) u pi/16 folded into the first octant: only JM_A0 and JM_C1..JM_C7 occur
+    int a = ((2 * n + 1) * u) & 31;
+    a = a > 16 ? 32 - a : a;
+    const bool neg = a > 8;
+    a = neg ? 16 - a : a;
+    const double m = (a == 0 || a == 4) ? JM_A0 : a == 1 ? JM_C1 : a == 2 ? JM_C2 : a == 3 ? JM_C3
+                     : a == 5 ? JM_C5 : a == 6 ? JM_C6 : JM_C7;
+    const float f = (float)(scale * m);
+    return neg ? -f : f;
+}
+
+// The order in which the second MFMA pass visits the 8 entries of a block's
+// contraction index: pass one leaves index i = 4*(lane>>4) + reg in accumulator
+// register `reg`, and register r feeds K-step r of pass two, where lane group g
+// supplies i = 4g + r.
+JM_HD int jm_mfma_k_order(int step) // step 0..7 -> index 0,4,1,5,2,6,3,7
+{
+    return (step & 1) * 4 + (step >> 1);
+}
+
+// Level shift folded into the accumulator of the first forward pass (recenterAroundZero,
+// :289-298): -128 * sum_n m(0, n) for u = 0, nothing for the other rows.
+#define JM_LEVEL_DC (-362.03867196751236f) /* -128 * 8 / (2 sqrt 2) */
+
+// px: 64 pixel values 0..255 (row-major) -> 100 * DCT coefficients (natural order)
+JM_HD void jm_mfma_fdct_block(const float (&px)[64], float (&out)[64])
+{
+    float z[64]; // z[u*8 + x]: vertical pass, contraction over the row index y, ascending
+    for (int u = 0; u < 8; ++u)
+        for (int x = 0; x < 8; ++x) {
+            float acc = u == 0 ? JM_LEVEL_DC : 0.0f;
+            for (int y = 0; y < 8; ++y)
+                acc = jm_fma(px[y * 8 + x], jm_dct_basis(u, y, 1.0), acc);
+            z[u * 8 + x] = acc;
+        }
+    for (int u = 0; u < 8; ++u) // horizontal pass, scaled by 100, contraction over x
+        for (int v = 0; v < 8; ++v) {
+            float acc = 0.0f;
+            for (int st = 0; st < 8; ++st) {
+                const int x = jm_mfma_k_order(st);
+                acc = jm_fma(z[u * 8 + x], jm_dct_basis(v, x, 100.0), acc);
+            }
+            out[u * 8 + v] = acc;
+        }
+}
+
+// w: 64 dequantised coefficients (natural order) -> 0.25*sum of :591 (before rounding)
+JM_HD void jm_mfma_idct_block(const float (&w)[64], float (&out)[64])
+{
+    float t[64]; // t[u*8 + x]: contraction over v, ascending
+    for (int u = 0; u < 8; ++u)
+        for (int x = 0; x < 8; ++x) {
+            float acc = 0.0f;
+            for (int v = 0; v < 8; ++v)
+                acc = jm_fma(w[u * 8 + v], jm_dct_basis(v, x, 1.0), acc);
+            t[u * 8 + x] = acc;
+        }
+    for (int y = 0; y < 8; ++y) // contraction over u in the register-fed order
+        for (int x = 0; x < 8; ++x) {
+            float acc = 0.0f;
+            for (int st = 0; st < 8; ++st) {
+                const int u = jm_mfma_k_order(st);
+                acc = jm_fma(jm_dct_basis(u, y, 1.0), t[u * 8 + x], acc);
+            }
+            out[y * 8 + x] = acc;
+        }
+}
+
 // ------------------------------------------------------------------ quantise
 // x100 = 100 * (0.25*cu*cv*sum) as produced by the two forward passes (the
 // second one scaled by 100).  Follows the reference bit for bit from there:

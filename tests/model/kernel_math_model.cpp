@@ -140,6 +140,36 @@ long jmm_check_inv_chroma_fast(long *n_flagged)
     return bad;
 }
 
+// the matrix-core transform order (jm_mfma_*): same contracts as the two above
+void jmm_mfma_fdct_quant_blocks(const int32_t *px, size_t nb, const int32_t *q, int32_t *out)
+{
+    JmQuantTab tab;
+    jm_make_quant_tab(q, tab);
+    for (size_t b = 0; b < nb; ++b) {
+        float v[64], c[64];
+        for (int i = 0; i < 64; ++i)
+            v[i] = (float)px[b * 64 + i];
+        jm_mfma_fdct_block(v, c);
+        jm_quantise_block(c, tab);
+        for (int i = 0; i < 64; ++i)
+            out[b * 64 + i] = jm_magic_to_int(c[i]);
+    }
+}
+
+void jmm_mfma_dequant_idct_blocks(const int32_t *coef, size_t nb, const int32_t *q, int32_t *out)
+{
+    for (size_t b = 0; b < nb; ++b) {
+        float w[64], x[64];
+        for (int i = 0; i < 64; ++i)
+            w[i] = (float)coef[b * 64 + i] * (float)q[i];
+        jm_mfma_idct_block(w, x);
+        for (int i = 0; i < 64; ++i)
+            out[b * 64 + i] = jm_magic_to_int(jm_pixel_magic(x[i]));
+    }
+}
+
+float jmm_dct_basis(int u, int n, double scale) { return jm_dct_basis(u, n, scale); }
+
 const uint8_t *jmm_zigzag(void) { return kZigzag; }
 
 // every possible quad sum 0..1020 through the kernels' truncating-mean helper

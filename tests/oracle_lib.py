@@ -300,6 +300,20 @@ class KernelMathModel:
         self.lib.jmm_dequant_idct_blocks(_p(coef), C.c_size_t(coef.shape[0]), _p(q), _p(out))
         return out
 
+    def mfma_fdct_quant_blocks(self, px, q):
+        px = np.ascontiguousarray(px, np.int32).reshape(-1, 64)
+        out = np.empty_like(px)
+        q = np.ascontiguousarray(q, np.int32)
+        self.lib.jmm_mfma_fdct_quant_blocks(_p(px), C.c_size_t(px.shape[0]), _p(q), _p(out))
+        return out
+
+    def mfma_dequant_idct_blocks(self, coef, q):
+        coef = np.ascontiguousarray(coef, np.int32).reshape(-1, 64)
+        out = np.empty_like(coef)
+        q = np.ascontiguousarray(q, np.int32)
+        self.lib.jmm_mfma_dequant_idct_blocks(_p(coef), C.c_size_t(coef.shape[0]), _p(q), _p(out))
+        return out
+
 
 def plane_to_blocks(plane):
     """extractBlocks layout (zero fill) as int32 [nb, 64]."""

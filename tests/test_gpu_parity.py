@@ -63,7 +63,9 @@ def _model_image(model, orc, bgr, qy, qc):
     planes = orc.chroma_subsample(ycc)
     out = []
     for pl, q in zip(planes, (qy, qc, qc)):
-        nat = model.fdct_quant_blocks(plane_to_blocks(pl), q)
+        # JPEGAMD_TRANSFORM=mfma: the fused encoder's transform runs on the matrix cores
+        fdct = model.mfma_fdct_quant_blocks if os.environ.get("JPEGAMD_TRANSFORM") == "mfma" else model.fdct_quant_blocks
+        nat = fdct(plane_to_blocks(pl), q)
         out.append(nat[:, ZIGZAG].astype(np.int16))
     return out
 
@@ -127,6 +129,23 @@ def test_image_vs_oracle(gpu, orc, model, kind, seed, rows, cols, qf):
     _check_px(rec, want_px, f"{kind} decode", lsb=2)
     if kind == "gray":
         assert (coefs[1] == 0).all() and (coefs[2] == 0).all()
+
+
+def test_matrix_core_encoder_variant(gpu, orc, model, monkeypatch):
+    """JPEGAMD_TRANSFORM=mfma: the opt-in encoder whose DCT runs as v_mfma_f32_16x16x4_f32
+    chains.  An f32 MFMA is a k-ordered fma chain, so it must equal the host replay
+    (jm_mfma_fdct_block) bit for bit, and the oracle within the usual bar."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    monkeypatch.setenv("JPEGAMD_TRANSFORM", "mfma")
+    for kind, seed, rows, cols, qf in (("photo", 21, 64, 1040, 50), ("noise", 22, 48, 528, 90), ("photo", 23, 32, 16, 100)):
+        qy, qc = jpeg_amd.quality_tables(qf)
+        bgr = synth_image(rows, cols, seed, kind).numpy()
+        coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)]
+        for g, w, n in zip(coefs, orc.encode_image(bgr, qy, qc), "Y Cb Cr".split()):
+            _check_coef(g, w, n)
+        for g, m in zip(coefs, _model_image(model, orc, bgr, qy, qc)):
+            assert np.array_equal(g, m), "matrix-core kernel differs from its host replay"
 
 
 def test_colour_wrap_quirk(gpu, orc):
