@@ -61,6 +61,24 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// byte J of w as a float, opaque to the optimiser: left to itself LLVM turns the first
+// butterfly level of the DCT into SDWA integer adds plus one conversion per SUM, which
+// costs more slow-rate instructions than converting the eight inputs
+template <int J>
+__device__ __forceinline__ float ubyte_f32(uint32_t w)
+{
+    float f;
+    if (J == 0)
+        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w));
+    else if (J == 1)
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w));
+    else if (J == 2)
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+    else
+        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w));
+    return f;
+}
+
 __device__ __forceinline__ int u3_byte(const U3 &v, int idx)
 {
     uint32_t w = idx < 4 ? v.a : (idx < 8 ? v.b : v.c);
@@ -243,11 +261,10 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 uint2 d = *reinterpret_cast<const uint2 *>(src + r * pitch);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[r * 8 + j] = (float)((d.x >> (8 * j)) & 0xFFu);
-                    v[r * 8 + 4 + j] = (float)((d.y >> (8 * j)) & 0xFFu);
-                }
+                v[r * 8 + 0] = ubyte_f32<0>(d.x), v[r * 8 + 1] = ubyte_f32<1>(d.x);
+                v[r * 8 + 2] = ubyte_f32<2>(d.x), v[r * 8 + 3] = ubyte_f32<3>(d.x);
+                v[r * 8 + 4] = ubyte_f32<0>(d.y), v[r * 8 + 5] = ubyte_f32<1>(d.y);
+                v[r * 8 + 6] = ubyte_f32<2>(d.y), v[r * 8 + 7] = ubyte_f32<3>(d.y);
             }
             block_fdct_quant(v, qtab + (luma ? 0 : 64));
             // The staging area aliases the Y rows.  LDS instructions of one wave
