@@ -423,9 +423,13 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
                     const int cb0 = (int)(cbp & 0xFFu), cb1 = (int)(cbp >> 8);
                     const int cr0 = (int)(crp & 0xFFu), cr1 = (int)(crp >> 8);
                     const JmChromaPk c0 = jm_inv_chroma_pk_fast<0>(cbp, crp), c1 = jm_inv_chroma_pk_fast<1>(cbp, crp);
-                    U3 wa, wb;
-                    jm_inv_row4(ya, c0, c1, cb0, cr0, cb1, cr1, wa.a, wa.b, wa.c);
-                    jm_inv_row4(yb, c0, c1, cb0, cr0, cb1, cr1, wb.a, wb.b, wb.c);
+                    U3 wa, wb; // both rows in one straight-line block, one tie test for the task
+                    jm_inv_row4_fast(ya, c0, c1, wa.a, wa.b, wa.c);
+                    jm_inv_row4_fast(yb, c0, c1, wb.a, wb.b, wb.c);
+                    if (__builtin_expect((c0.tie | c1.tie) < 0, 0)) {
+                        jm_inv_row4_exact(ya, cb0, cr0, cb1, cr1, wa.a, wa.b, wa.c);
+                        jm_inv_row4_exact(yb, cb0, cr0, cb1, cr1, wb.a, wb.b, wb.c);
+                    }
                     uint8_t *p0 = bgr + (size_t)(row_base + 2 * rp) * stride + (size_t)x * 3;
                     *reinterpret_cast<U3 *>(p0) = wa;
                     *reinterpret_cast<U3 *>(p0 + stride) = wb;

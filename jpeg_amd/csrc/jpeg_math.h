@@ -616,10 +616,10 @@ JM_HD uint32_t jm_ypair(uint32_t y4) // {Y_I, Y_J} as uint16 pair from four pack
 }
 
 // four pixels of one row (Y bytes y4), pixels 0,1 under chroma sample a and 2,3
-// under b -> 12 output bytes.  Tie pixels are redone by the reference's double
-// sequence (jm_inv_colour_f64); cba/cra/cbb/crb are only read on that path.
-JM_HD void jm_inv_row4(uint32_t y4, const JmChromaPk &a, const JmChromaPk &b,
-                       int cba, int cra, int cbb, int crb, uint32_t &w0, uint32_t &w1, uint32_t &w2)
+// under b -> 12 output bytes: one packed add + one saturating pack per two bytes.
+// Valid unless a.tie or b.tie is flagged (< 0); then use jm_inv_row4_exact.
+JM_HD void jm_inv_row4_fast(uint32_t y4, const JmChromaPk &a, const JmChromaPk &b,
+                            uint32_t &w0, uint32_t &w1, uint32_t &w2)
 {
     uint32_t h0 = jm_add_sat_u8x2(jm_ypair<0, 0>(y4), a.d01);
     uint32_t h1 = jm_add_sat_u8x2(jm_ypair<0, 1>(y4), a.d20);
@@ -630,18 +630,31 @@ JM_HD void jm_inv_row4(uint32_t y4, const JmChromaPk &a, const JmChromaPk &b,
     w0 = jm_pack_lo16(h0, h1);
     w1 = jm_pack_lo16(h2, h3);
     w2 = jm_pack_lo16(h4, h5);
-    if (__builtin_expect((a.tie | b.tie) < 0, 0)) {
-        uint8_t o[12];
-        for (int j = 0; j < 4; ++j) {
-            const int y = (int)((y4 >> (8 * j)) & 0xFFu);
-            const int cb = j < 2 ? cba : cbb, cr = j < 2 ? cra : crb;
-            const JmChromaTerm t = jm_inv_chroma(cb, cr);
-            int o0, o1, o2;
-            jm_inv_colour(y, cb, cr, t, o0, o1, o2);
-            o[3 * j] = (uint8_t)o0, o[3 * j + 1] = (uint8_t)o1, o[3 * j + 2] = (uint8_t)o2;
-        }
-        w0 = o[0] | (o[1] << 8) | (o[2] << 16) | ((uint32_t)o[3] << 24);
-        w1 = o[4] | (o[5] << 8) | (o[6] << 16) | ((uint32_t)o[7] << 24);
-        w2 = o[8] | (o[9] << 8) | (o[10] << 16) | ((uint32_t)o[11] << 24);
+}
+
+// the same four pixels by the exact path: integer chroma terms, and the reference's
+// double sequence (jm_inv_colour_f64) for the channels that are exact ties
+JM_HD void jm_inv_row4_exact(uint32_t y4, int cba, int cra, int cbb, int crb,
+                             uint32_t &w0, uint32_t &w1, uint32_t &w2)
+{
+    uint8_t o[12];
+    for (int j = 0; j < 4; ++j) {
+        const int y = (int)((y4 >> (8 * j)) & 0xFFu);
+        const int cb = j < 2 ? cba : cbb, cr = j < 2 ? cra : crb;
+        const JmChromaTerm t = jm_inv_chroma(cb, cr);
+        int o0, o1, o2;
+        jm_inv_colour(y, cb, cr, t, o0, o1, o2);
+        o[3 * j] = (uint8_t)o0, o[3 * j + 1] = (uint8_t)o1, o[3 * j + 2] = (uint8_t)o2;
     }
+    w0 = o[0] | (o[1] << 8) | (o[2] << 16) | ((uint32_t)o[3] << 24);
+    w1 = o[4] | (o[5] << 8) | (o[6] << 16) | ((uint32_t)o[7] << 24);
+    w2 = o[8] | (o[9] << 8) | (o[10] << 16) | ((uint32_t)o[11] << 24);
+}
+
+JM_HD void jm_inv_row4(uint32_t y4, const JmChromaPk &a, const JmChromaPk &b,
+                       int cba, int cra, int cbb, int crb, uint32_t &w0, uint32_t &w1, uint32_t &w2)
+{
+    jm_inv_row4_fast(y4, a, b, w0, w1, w2);
+    if (__builtin_expect((a.tie | b.tie) < 0, 0))
+        jm_inv_row4_exact(y4, cba, cra, cbb, crb, w0, w1, w2);
 }
