@@ -212,11 +212,17 @@ JM_HD void jm_fdct8(float &x0, float &x1, float &x2, float &x3,
 }
 
 // x_n = sum_u (c_u/2) X_u cos((2n+1)u*pi/16)
+// SHRINK: every constant carries a factor (1 - 1.5e-7), i.e. the outputs come out
+// pulled toward zero by about two ulps -- the second inverse pass uses it so that the
+// pixel rounding needs no separate shrink step (see jm_pixel_magic).
+template <bool SHRINK>
 JM_HD void jm_idct8(float &x0, float &x1, float &x2, float &x3,
                     float &x4, float &x5, float &x6, float &x7)
 {
-    constexpr float A0 = (float)JM_A0, C1 = (float)JM_C1, C2 = (float)JM_C2, C3 = (float)JM_C3,
-                    C5 = (float)JM_C5, C6 = (float)JM_C6, C7 = (float)JM_C7;
+    constexpr double K = SHRINK ? 1.0 - 1.5e-7 : 1.0;
+    constexpr float A0 = (float)(K * JM_A0), C1 = (float)(K * JM_C1), C2 = (float)(K * JM_C2),
+                    C3 = (float)(K * JM_C3), C5 = (float)(K * JM_C5), C6 = (float)(K * JM_C6),
+                    C7 = (float)(K * JM_C7);
     float p0 = A0 * (x0 + x4), p1 = A0 * (x0 - x4);
     float r0 = jm_fma(C2, x2, C6 * x6), r1 = jm_fma(C6, x2, -(C2 * x6));
     float e0 = p0 + r0, e3 = p0 - r0, e1 = p1 + r1, e2 = p1 - r1;
@@ -426,6 +432,11 @@ JM_HD float jm_pixel_magic(float x)
 {
     float z = jm_fma(x, -1.5e-7f, x);
     return z + (JM_MAGIC + 128.0f);
+}
+// the same for an x that already carries the shrink (jm_idct8<true> as the last pass)
+JM_HD float jm_pixel_magic_preshrunk(float x)
+{
+    return x + (JM_MAGIC + 128.0f);
 }
 
 JM_HD int jm_magic_to_int(float u)

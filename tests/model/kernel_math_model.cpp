@@ -108,13 +108,13 @@ void jmm_dequant_idct_blocks(const int32_t *coef, size_t nb, const int32_t *q, i
         for (int i = 0; i < 64; ++i)
             v[i] = (float)coef[b * 64 + i] * (float)q[i];
         for (int c = 0; c < 8; ++c)
-            jm_idct8(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
+            jm_idct8<false>(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
                      v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
         for (int r = 0; r < 8; ++r)
-            jm_idct8(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3],
+            jm_idct8<true>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3],
                      v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
         for (int i = 0; i < 64; ++i)
-            out[b * 64 + i] = jm_magic_to_int(jm_pixel_magic(v[i]));
+            out[b * 64 + i] = jm_magic_to_int(jm_pixel_magic_preshrunk(v[i]));
     }
 }
 
