@@ -47,6 +47,9 @@ constexpr int kStageBytes = 64 * kStagePitch; // 9216
 constexpr int kChromaBytes = 2 * 8 * 256;     // Cb + Cr, 8 rows x 256 samples
 constexpr int kWaveLds = kStageBytes + kChromaBytes; // 13312
 constexpr int kWavesPerWg = 4;
+#ifndef ENC_AHEAD
+#define ENC_AHEAD 3
+#endif
 
 struct __attribute__((aligned(4))) U3 {
     uint32_t a, b, c;
@@ -198,9 +201,15 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
             b = *reinterpret_cast<const U3 *>(p + stride);
         }
     };
-    U3 cur_a = {0, 0, 0}, cur_b = {0, 0, 0}, nxt_a = {0, 0, 0}, nxt_b = {0, 0, 0};
-    task_load(0, cur_a, cur_b);
-    task_load(1, nxt_a, nxt_b);
+    // kAhead tasks of loads are in flight behind the one being converted: HBM latency
+    // under load is several microseconds, a task is about a quarter of one
+    constexpr int kAhead = ENC_AHEAD;
+    U3 ring_a[kAhead], ring_b[kAhead]; // [0] = the current task (rotated by moves, never indexed dynamically)
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) {
+        ring_a[i] = ring_b[i] = U3{0, 0, 0};
+        task_load(i, ring_a[i], ring_b[i]);
+    }
 
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
@@ -210,8 +219,8 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
             for (int t = 0; t < 8; ++t) {
                 const int T = it * 8 + t;
                 U3 far_a = {0, 0, 0}, far_b = {0, 0, 0};
-                if (T + 2 < 16)
-                    task_load(T + 2, far_a, far_b);
+                if (T + kAhead < 16)
+                    task_load(T + kAhead, far_a, far_b);
                 const int rp = t >> 1;
                 const int g = lane + 64 * (t & 1);
                 if (x0 + 4 * g < cols) {
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                         JmFwdTies tie[2];
 #pragma unroll
                         for (int row = 0; row < 2; ++row) {
-                            const U3 &px = row ? cur_b : cur_a;
+                            const U3 &px = row ? ring_b[0] : ring_a[0];
                             p[row][0] = (float)u3_byte(px, 3 * j), p[row][1] = (float)u3_byte(px, 3 * j + 1);
                             p[row][2] = (float)u3_byte(px, 3 * j + 2);
                             jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
@@ -253,8 +262,12 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                     *reinterpret_cast<uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g) = (uint16_t)jm_pack_lo8x4(
                         jm_quad_mean_magic(sum_r[0]), jm_quad_mean_magic(sum_r[1]), 0.f, 0.f);
                 }
-                cur_a = nxt_a, cur_b = nxt_b;
-                nxt_a = far_a, nxt_b = far_b;
+                // (rolling the loop and rotating by moves beats unrolling it by the ring size:
+                // measured 123 vs 140 us)
+#pragma unroll
+                for (int i = 0; i + 1 < kAhead; ++i)
+                    ring_a[i] = ring_a[i + 1], ring_b[i] = ring_b[i + 1];
+                ring_a[kAhead - 1] = far_a, ring_b[kAhead - 1] = far_b;
             }
         }
         wave_lds_fence();
