@@ -47,9 +47,6 @@ constexpr int kStageBytes = 64 * kStagePitch; // 9216
 constexpr int kChromaBytes = 2 * 8 * 256;     // Cb + Cr, 8 rows x 256 samples
 constexpr int kWaveLds = kStageBytes + kChromaBytes; // 13312
 constexpr int kWavesPerWg = 4;
-#ifndef ENC_AHEAD
-#define ENC_AHEAD 3
-#endif
 
 struct __attribute__((aligned(4))) U3 {
     uint32_t a, b, c;
@@ -185,42 +182,43 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     const int x0 = tx * kWaveTileW;
     const int bw_y = cols >> 3, bw_c = cols >> 4;
 
-    // BGR rows stream through three register slots (two tasks of loads in
-    // flight behind the one being converted).  Task T = 8*it + t covers
+    // BGR rows are double-buffered in registers four tasks at a time: while the four tasks
+    // of one buffer are converted, the loads of the next four are in flight (HBM latency
+    // under load is several tasks long).  The inner four tasks are unrolled so that every
+    // slot is a fixed register; the buffers swap by moves once per four tasks, by which
+    // time the loads issued four tasks earlier have landed.  Task T = 8*it + t covers
     // 2 rows x 4 pixels per lane: row pair rp = t>>1, pixel group g = lane + 64*(t&1).
-    auto task_ptr = [&](int T) -> const uint8_t * {
+    // Loads are unconditional: lanes beyond the image edge re-read its last pixel group,
+    // tasks beyond 15 re-read task 15.
+    constexpr int kRing = 4;
+    auto task_load = [&](int T, U3 &a, U3 &b) {
+        T = T < 15 ? T : 15;
         const int t = T & 7;
         const int row = ty * 16 + (T >> 3) * 8 + 2 * (t >> 1);
-        const int x = x0 + 4 * (lane + 64 * (t & 1));
-        return x < cols ? bgr + (size_t)row * stride + (size_t)x * 3 : nullptr;
+        int x = x0 + 4 * (lane + 64 * (t & 1));
+        x = x < cols - 4 ? x : cols - 4;
+        const uint8_t *p = bgr + (size_t)row * stride + (size_t)x * 3;
+        a = *reinterpret_cast<const U3 *>(p);
+        b = *reinterpret_cast<const U3 *>(p + stride);
     };
-    auto task_load = [&](int T, U3 &a, U3 &b) {
-        const uint8_t *p = task_ptr(T);
-        if (p) {
-            a = *reinterpret_cast<const U3 *>(p);
-            b = *reinterpret_cast<const U3 *>(p + stride);
-        }
-    };
-    // kAhead tasks of loads are in flight behind the one being converted: HBM latency
-    // under load is several microseconds, a task is about a quarter of one
-    constexpr int kAhead = ENC_AHEAD;
-    U3 ring_a[kAhead], ring_b[kAhead]; // [0] = the current task (rotated by moves, never indexed dynamically)
+    U3 ring_a[kRing], ring_b[kRing];
 #pragma unroll
-    for (int i = 0; i < kAhead; ++i) {
-        ring_a[i] = ring_b[i] = U3{0, 0, 0};
+    for (int i = 0; i < kRing; ++i)
         task_load(i, ring_a[i], ring_b[i]);
-    }
 
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
         if (it < 2) {
             // ---- colour + 4:2:0 for tile rows 8*it .. 8*it+7 -----------------
 #pragma unroll 1
-            for (int t = 0; t < 8; ++t) {
-                const int T = it * 8 + t;
-                U3 far_a = {0, 0, 0}, far_b = {0, 0, 0};
-                if (T + kAhead < 16)
-                    task_load(T + kAhead, far_a, far_b);
+            for (int t0 = 0; t0 < 8; t0 += kRing) {
+            U3 next_a[kRing], next_b[kRing];
+#pragma unroll
+            for (int i = 0; i < kRing; ++i)
+                task_load(it * 8 + t0 + kRing + i, next_a[i], next_b[i]);
+#pragma unroll
+            for (int slot = 0; slot < kRing; ++slot) {
+                const int t = t0 + slot;
                 const int rp = t >> 1;
                 const int g = lane + 64 * (t & 1);
                 if (x0 + 4 * g < cols) {
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                         JmFwdTies tie[2];
 #pragma unroll
                         for (int row = 0; row < 2; ++row) {
-                            const U3 &px = row ? ring_b[0] : ring_a[0];
+                            const U3 &px = row ? ring_b[slot] : ring_a[slot];
                             p[row][0] = (float)u3_byte(px, 3 * j), p[row][1] = (float)u3_byte(px, 3 * j + 1);
                             p[row][2] = (float)u3_byte(px, 3 * j + 2);
                             jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
@@ -262,12 +260,10 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                     *reinterpret_cast<uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g) = (uint16_t)jm_pack_lo8x4(
                         jm_quad_mean_magic(sum_r[0]), jm_quad_mean_magic(sum_r[1]), 0.f, 0.f);
                 }
-                // (rolling the loop and rotating by moves beats unrolling it by the ring size:
-                // measured 123 vs 140 us)
+            }
 #pragma unroll
-                for (int i = 0; i + 1 < kAhead; ++i)
-                    ring_a[i] = ring_a[i + 1], ring_b[i] = ring_b[i + 1];
-                ring_a[kAhead - 1] = far_a, ring_b[kAhead - 1] = far_b;
+            for (int i = 0; i < kRing; ++i)
+                ring_a[i] = next_a[i], ring_b[i] = next_b[i];
             }
         }
         wave_lds_fence();
