@@ -249,16 +249,22 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                         sum_b[j >> 1] += cb[0] + cb[1];
                         sum_r[j >> 1] += cr[0] + cr[1];
                     }
-                    *reinterpret_cast<uint32_t *>(stage + (2 * rp) * 512 + 4 * g) =
-                        jm_pack_lo8x4(ya[0], ya[1], ya[2], ya[3]);
-                    *reinterpret_cast<uint32_t *>(stage + (2 * rp + 1) * 512 + 4 * g) =
-                        jm_pack_lo8x4(yb[0], yb[1], yb[2], yb[3]);
+                    // bytes go to LDS one by one (the low byte of each magic float): byte stores
+                    // ride the LDS queue, packing them first would cost ten VALU permutes
+                    uint8_t *y0 = stage + (2 * rp) * 512 + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        y0[j] = (uint8_t)jm_bits(ya[j]);
+                        y0[512 + j] = (uint8_t)jm_bits(yb[j]);
+                    }
                     // chromaSubsampling: truncating mean of the quad (:139-149)
                     const int crow = it * 4 + rp;
-                    *reinterpret_cast<uint16_t *>(cbuf + crow * 256 + 2 * g) = (uint16_t)jm_pack_lo8x4(
-                        jm_quad_mean_magic(sum_b[0]), jm_quad_mean_magic(sum_b[1]), 0.f, 0.f);
-                    *reinterpret_cast<uint16_t *>(cbuf + 2048 + crow * 256 + 2 * g) = (uint16_t)jm_pack_lo8x4(
-                        jm_quad_mean_magic(sum_r[0]), jm_quad_mean_magic(sum_r[1]), 0.f, 0.f);
+                    uint8_t *c0 = cbuf + crow * 256 + 2 * g;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        c0[q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[q]));
+                        c0[2048 + q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_r[q]));
+                    }
                 }
             }
 #pragma unroll

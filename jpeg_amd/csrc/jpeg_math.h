@@ -464,7 +464,7 @@ JM_HD uint32_t jm_pack4_u8(float a, float b, float c, float d)
 // Forward: the same decision as jm_fwd_colour (exact rational rounding, with
 // exact x.5 ties handed to the reference's double sequence), but the common
 // case runs on float fma/add only.
-//   Y      direct float chain (error < 1e-4; the rational values are 1e-3 apart).
+//   Y      float chain of value + 5e-4 (error < 5e-5; the rational values are 1e-3 apart).
 //   Cb, Cr centred chains  s = value - 128 + 5e-5  (error < 2e-5; the rational
 //          values are 1e-4 apart).  The bias makes the magic add round exact ties
 //          UP, which is what round() does unless the double sequence lands below
@@ -479,12 +479,15 @@ struct JmFwdTies {
 };
 #define JM_CHROMA_BIAS 5.0e-5f
 
+#define JM_LUMA_BIAS 5.0e-4f
+
 JM_HD void jm_fwd_colour_fast(float p0, float p1, float p2, float &uy, float &cb, float &cr, JmFwdTies &t)
 {
-    t.sy = jm_fma(p2, 0.114f, jm_fma(p1, 0.587f, p0 * 0.299f));
+    // Y: value + 5e-4 (the rational values are 1e-3 apart, the chain's error is below
+    // 5e-5), so exact ties round UP here too and show as a residual of -0.5 + 5e-4
+    t.sy = jm_fma(p2, 0.114f, jm_fma(p1, 0.587f, jm_fma(p0, 0.299f, JM_LUMA_BIAS)));
     uy = t.sy + JM_MAGIC;
-    float ry = t.sy - (uy - JM_MAGIC);
-    t.ty = 0.4995f - __builtin_fabsf(ry);
+    t.ty = (t.sy - (uy - JM_MAGIC)) + 0.499f;
     t.sb = jm_fma(p2, 0.5f, jm_fma(p1, -0.3313f, jm_fma(p0, -0.1687f, JM_CHROMA_BIAS)));
     cb = (t.sb + JM_MAGIC) - JM_MAGIC;
     t.tb = (t.sb - cb) + 0.4999f; // residual of a tie is -0.5 + bias
@@ -504,6 +507,11 @@ JM_HD bool jm_fwd_any_tie(const JmFwdTies &t)
 // (value - 128); 256 wraps to 0, i.e. -128 centred.
 JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, float &uy, float &cb, float &cr)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the conversions on the floats at hand (left alone, the compiler goes back to
+    // the packed bytes: eight more instructions per visit)
+    asm("" : "+v"(p0), "+v"(p1), "+v"(p2));
+#endif
     const double d0 = (double)p0, d1 = (double)p1, d2 = (double)p2;
     if ((int32_t)jm_bits(t.ty) < 0) {
         double v = 0.299 * d0; // 0.0 + x is exact
