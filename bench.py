@@ -157,7 +157,7 @@ def main():
                                                       / ((enc_ms + dec_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roundtrip_mse": mse,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N=1 figure
             # bounded sample: about 20 s of single-thread oracle work = one whole 8192^2 image
             crop_r, crop_c = min(rows, 8192), min(cols, 8192)
             host = bgr[:crop_r, :crop_c].contiguous().cpu().numpy()
