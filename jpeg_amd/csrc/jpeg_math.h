@@ -341,18 +341,6 @@ JM_HD int jm_snap_quant(float x100, float q, float rcp_q)
     return (int)jm_round_half_away(v); // (int)(-0.0f) == 0
 }
 
-// ------------------------------------------------------------- pixel rounding
-// x = 0.25*sum of encode_decode.cpp:591 as produced by the two inverse passes.
-// The reference's accumulation makes exact x.5 ties (frequent for DC-only
-// chroma blocks) fall toward zero, because float(1/sqrt(2))^2 = 0.49999997;
-// a 1e-5 pull toward zero before round-to-nearest reproduces that
-// (SURVEY.md 8a-12).  Returns round(...) + 128, unclamped.
-JM_HD int jm_round_pixel(float x)
-{
-    float y = x - jm_copysign(1.0e-5f, x);
-    return (int)jm_rint(y) + 128;
-}
-
 // ===========================================================================
 // Block-level fast paths.  gfx950 issues v_fma/v_mul/v_add/v_sub (f32),
 // v_add/v_sub (int), and/or/xor and right shifts at full rate, and nearly

@@ -1,0 +1,96 @@
+"""The measurement configurations of SURVEY.md 8d at sizes the oracle finishes in
+seconds: the quality sweep (config 5), the gray / odd-size case (config 3) and the
+batch of independent images (config 4).  Same bars as tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _check_coef, _check_px, _t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("qf", [1, 5, 10, 25, 37, 49, 50, 51, 63, 75, 90, 95, 99, 100])
+def test_quality_sweep(gpu, orc, qf):
+    """config 5: every branch of the table scaling (main.cpp:51-80: qf < 50, qf >= 50,
+    the clamps to 1 and to 255) through encode -> .bin -> decode against the oracle."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    qy, qc = jpeg_amd.quality_tables(qf)
+    oy, oc = orc.quality_tables(qf)
+    assert np.array_equal(qy, oy) and np.array_equal(qc, oc)
+    bgr = synth_image(128, 256, 1000 + qf, "photo").numpy()
+    want = orc.encode_image(bgr, qy, qc)
+    got = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)]
+    same = True
+    for g, w, n in zip(got, want, "Y Cb Cr".split()):
+        same &= _check_coef(g, w, f"QF={qf} {n}") == 0
+    data = jpeg_amd.compress_image(bgr, qy, qc)
+    if same:  # then the file is the reference's, byte for byte
+        assert data == orc.write_bin(*(orc.rle_stream(c) for c in want), 128, 256)
+    rec = jpeg_amd.decompress_image(data, qy, qc)
+    _check_px(rec, orc.decode_image(*[np.asarray(g) for g in got], 128, 256, qy, qc), f"QF={qf} decode", lsb=2)
+
+
+def test_gray_image_has_flat_chroma(gpu, orc):
+    """config 3: B = G = R.  Y equals the gray value, Cb = Cr = 128, so every chroma
+    block is all zero after the level shift and its run-length stream is (0, 64)."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    rows, cols = 112, 336
+    qy, qc = jpeg_amd.quality_tables(90)
+    bgr = synth_image(rows, cols, 3, "gray").numpy()
+    assert np.array_equal(bgr[..., 0], bgr[..., 1]) and np.array_equal(bgr[..., 1], bgr[..., 2])
+    cy, ccb, ccr = jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)
+    assert int(ccb.abs().sum()) == 0 and int(ccr.abs().sum()) == 0
+    pairs, offs = jpeg_amd.rle_encode_plane(ccb)
+    assert pairs.shape[0] == ccb.shape[0] and bool((pairs[:, 0] == 0).all()) and bool((pairs[:, 1] == 64).all())
+    for g, w, n in zip((cy, ccb, ccr), orc.encode_image(bgr, qy, qc), "Y Cb Cr".split()):
+        _check_coef(g.cpu().numpy(), w, n)
+    rec = jpeg_amd.decode_image(cy, ccb, ccr, rows, cols, qy, qc).cpu().numpy()
+    assert np.array_equal(rec[..., 0], rec[..., 1]) and np.array_equal(rec[..., 1], rec[..., 2])
+
+
+def test_odd_plane_padding_branch(gpu, orc):
+    """config 3, second half: the zero-fill / drop branch of extractBlocks and the block
+    scatter (encode_decode.cpp:248-251, 702-703) is only reachable at the plane level."""
+    import jpeg_amd
+    rng = np.random.default_rng(33)
+    for rows, cols in ((3580 // 20, 5370 // 30), (1, 1), (7, 9), (8, 8), (9, 7), (17, 515)):
+        q = jpeg_amd.quality_tables(90)[0]
+        plane = rng.integers(0, 256, size=(rows, cols), dtype=np.uint8)
+        want, _ = orc.encode_plane(plane, q, want_symbols=False)
+        got = jpeg_amd.encode_plane(_t(plane, gpu), q).cpu().numpy()
+        _check_coef(got, want, f"{rows}x{cols} plane")
+        rec = jpeg_amd.decode_plane(_t(want, gpu), rows, cols, q).cpu().numpy()
+        _check_px(rec, orc.decode_plane(want, rows, cols, q), f"{rows}x{cols} plane decode")
+
+
+def test_batch_of_independent_images(gpu, orc):
+    """config 4: images are independent (no state survives a call): a batch encoded
+    back to back on one stream, and interleaved on two streams, equals one at a time."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    qy, qc = jpeg_amd.quality_tables(50)
+    rows, cols = 144, 256  # 3840x2160 scaled down by 15
+    imgs = [synth_image(rows, cols, seed, "photo", device=gpu) for seed in range(6)]
+    alone = []
+    for im in imgs:
+        alone.append([c.clone() for c in jpeg_amd.encode_image(im, qy, qc)])
+        torch.cuda.synchronize()
+    batch = [jpeg_amd.encode_image(im, qy, qc) for im in imgs]
+    torch.cuda.synchronize()
+    for a, b in zip(alone, batch):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for i, im in enumerate(imgs):
+        with torch.cuda.stream(s1 if i % 2 else s2):
+            outs.append(jpeg_amd.encode_image(im, qy, qc))
+    torch.cuda.synchronize()
+    for a, b in zip(alone, outs):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    want = orc.encode_image(imgs[0].cpu().numpy(), qy, qc)
+    for g, w, n in zip(alone[0], want, "Y Cb Cr".split()):
+        _check_coef(g.cpu().numpy(), w, n)
