@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstring>
 #include <queue>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -97,8 +98,8 @@ void assign_codes(const Tree &t, std::unordered_map<int, Code> &codes)
 struct BitWriter { // stringToBitstream's layout (:1093-1127): MSB first, last byte zero padded
     uint8_t *p;
     uint64_t acc = 0;
-    int n = 0;
-    explicit BitWriter(uint8_t *dst) : p(dst) {}
+    int n;
+    explicit BitWriter(uint8_t *dst, int lead_zero_bits = 0) : p(dst), n(lead_zero_bits) {}
     void put(uint64_t code, int len) // len <= 32 per call; the caller sized the buffer
     {
         acc = (acc << len) | code;
@@ -130,23 +131,86 @@ struct Plane {
 
 constexpr int kDense = 1 << 17; // symbols in [-65536, 65535] use flat tables
 
+// worker threads for the two passes over the symbols (host cores are otherwise idle
+// while this runs); small planes stay on the calling thread
+unsigned plane_threads(size_t n)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    hw = hw ? hw : 1;
+    const size_t want = n / (1u << 19) + 1; // about half a million symbols per thread
+    return (unsigned)std::min<size_t>(std::min<size_t>(want, hw), 16);
+}
+
+template <class F> void parallel_chunks(unsigned nt, F f) // f(chunk index)
+{
+    if (nt <= 1) {
+        f(0u);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; ++i)
+        th.emplace_back(f, i);
+    f(0u);
+    for (auto &t : th)
+        t.join();
+}
+
 int encode_plane(const int32_t *sym, size_t n, Plane &pl)
 {
+    const unsigned nt = plane_threads(n);
+    auto lo = [&](unsigned c) { return n * c / nt; };
+    auto dense = [](int s) { return s >= -kDense / 2 && s < kDense / 2; };
+
     // ---- frequency dictionary: counts + first-occurrence order ----------------
-    std::vector<int> count(kDense, 0);
+    // per chunk in parallel, then merged in chunk order: a symbol's first occurrence
+    // overall is its first occurrence in the earliest chunk that has it
+    std::vector<std::vector<int>> c_count(nt), c_order(nt);
+    std::vector<int> c_bad(nt, 0); // 1: symbol outside the dense window, 2: the internal marker
+    parallel_chunks(nt, [&](unsigned c) {
+        std::vector<int> &cnt = c_count[c];
+        cnt.assign(kDense, 0);
+        for (size_t i = lo(c), e = lo(c + 1); i < e; ++i) {
+            const int s = sym[i];
+            if (!dense(s)) {
+                c_bad[c] |= s == kInternal ? 2 : 1;
+                continue;
+            }
+            if (cnt[s + kDense / 2]++ == 0)
+                c_order[c].push_back(s);
+        }
+    });
+    int bad = 0;
+    for (int b : c_bad)
+        bad |= b;
+    if (bad & 2)
+        return fail("bin_encode: symbol 99999 collides with the reference's internal-node marker");
+    std::vector<int> &count = c_count[0];
     std::unordered_map<int, int> sparse; // symbols outside the dense window (never from the kernels)
     std::vector<int> order;
-    for (size_t i = 0; i < n; ++i) {
-        const int s = sym[i];
-        if (s == kInternal)
-            return fail("bin_encode: symbol 99999 collides with the reference's internal-node marker");
-        int &c = (s >= -kDense / 2 && s < kDense / 2) ? count[s + kDense / 2] : sparse[s];
-        if (c++ == 0)
-            order.push_back(s);
+    if (bad) { // rare general case: one serial pass over everything
+        count.assign(kDense, 0);
+        for (size_t i = 0; i < n; ++i) {
+            const int s = sym[i];
+            int &c = dense(s) ? count[s + kDense / 2] : sparse[s];
+            if (c++ == 0)
+                order.push_back(s);
+        }
+    } else {
+        std::vector<uint8_t> seen(kDense, 0);
+        for (unsigned c = 0; c < nt; ++c) {
+            for (int s : c_order[c])
+                if (!seen[s + kDense / 2]) {
+                    seen[s + kDense / 2] = 1;
+                    order.push_back(s);
+                }
+            if (c)
+                for (int s : c_order[c])
+                    count[s + kDense / 2] += c_count[c][s + kDense / 2];
+        }
     }
     std::unordered_map<int, int> freq; // the reference's container, same insertion sequence
     for (int s : order)
-        freq[s] = (s >= -kDense / 2 && s < kDense / 2) ? count[s + kDense / 2] : sparse[s];
+        freq[s] = dense(s) ? count[s + kDense / 2] : sparse[s];
     pl.dict.assign(freq.begin(), freq.end());
 
     // ---- tree and codes ---------------------------------------------------------
@@ -158,40 +222,70 @@ int encode_plane(const int32_t *sym, size_t n, Plane &pl)
     // ---- payload ----------------------------------------------------------------
     // flat (code, length) tables for the dense window when every code fits 32 bits
     bool fast = sparse.empty();
-    size_t longest = 0;
+    unsigned long long total_bits = 0;
     for (const auto &kv : codes) {
         fast = fast && kv.second.bits.size() <= 32;
-        longest = std::max(longest, kv.second.bits.size());
+        total_bits += (unsigned long long)kv.second.bits.size() * (unsigned long long)freq[kv.first];
     }
+    pl.payload.assign((size_t)((total_bits + 7) / 8) + 8, 0);
     if (fast) {
         std::vector<uint32_t> cbits(kDense, 0);
         std::vector<uint8_t> clen(kDense, 0);
-        unsigned long long total_bits = 0;
         for (const auto &kv : codes) {
             uint32_t v = 0;
             for (uint8_t b : kv.second.bits)
                 v = (v << 1) | b;
             cbits[kv.first + kDense / 2] = v;
             clen[kv.first + kDense / 2] = (uint8_t)kv.second.bits.size();
-            total_bits += (unsigned long long)kv.second.bits.size() * (unsigned long long)freq[kv.first];
         }
-        pl.payload.resize((size_t)((total_bits + 7) / 8) + 8);
-        BitWriter w(pl.payload.data());
-        for (size_t i = 0; i < n; ++i)
-            w.put(cbits[sym[i] + kDense / 2], clen[sym[i] + kDense / 2]);
-        pl.payload.resize((size_t)(w.finish() - pl.payload.data()));
+        // where each chunk's bits start: its symbols' code lengths, from the chunk's own counts
+        std::vector<unsigned long long> start(nt + 1, 0);
+        for (unsigned c = 0; c < nt; ++c) {
+            unsigned long long bits = 0;
+            if (nt == 1) {
+                bits = total_bits;
+            } else {
+                for (int s : c_order[c]) // (c_count[0] was merged into the totals: recount chunk 0 below)
+                    bits += c ? (unsigned long long)c_count[c][s + kDense / 2] * clen[s + kDense / 2] : 0;
+            }
+            start[c + 1] = bits;
+        }
+        if (nt > 1) { // chunk 0 = the total minus the others
+            unsigned long long others = 0;
+            for (unsigned c = 1; c < nt; ++c)
+                others += start[c + 1];
+            start[1] = total_bits - others;
+            for (unsigned c = 1; c < nt; ++c)
+                start[c + 1] += start[c];
+        }
+        // every chunk packs into its own buffer, starting inside its first byte; the
+        // buffers are then laid down in order, OR-ing the byte two chunks share
+        std::vector<std::vector<uint8_t>> part(nt);
+        parallel_chunks(nt, [&](unsigned c) {
+            const unsigned long long b0 = start[c], b1 = start[c + 1];
+            std::vector<uint8_t> &buf = part[c];
+            buf.assign((size_t)((b1 + 7) / 8 - b0 / 8) + 8, 0);
+            BitWriter w(buf.data(), (int)(b0 & 7));
+            for (size_t i = lo(c), e = lo(c + 1); i < e; ++i)
+                w.put(cbits[sym[i] + kDense / 2], clen[sym[i] + kDense / 2]);
+            buf.resize((size_t)(w.finish() - buf.data()));
+        });
+        for (unsigned c = 0; c < nt; ++c) {
+            if (part[c].empty())
+                continue;
+            uint8_t *dst = pl.payload.data() + start[c] / 8;
+            dst[0] |= part[c][0];
+            if (part[c].size() > 1)
+                std::memcpy(dst + 1, part[c].data() + 1, part[c].size() - 1);
+        }
+        pl.payload.resize((size_t)((total_bits + 7) / 8));
     } else {
-        unsigned long long total_bits = 0;
-        for (const auto &kv : codes)
-            total_bits += (unsigned long long)kv.second.bits.size() * (unsigned long long)freq[kv.first];
-        pl.payload.resize((size_t)((total_bits + 7) / 8) + 8);
         BitWriter w(pl.payload.data());
         for (size_t i = 0; i < n; ++i)
             for (uint8_t b : codes[sym[i]].bits)
                 w.put(b, 1);
         pl.payload.resize((size_t)(w.finish() - pl.payload.data()));
     }
-    (void)longest;
     if (pl.payload.size() > 0x7FFFFFFFu)
         return fail("bin_encode: payload exceeds the container's int32 length field");
     return 0;

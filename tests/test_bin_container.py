@@ -61,6 +61,22 @@ def test_random_streams_equal_the_oracle(orc):
                 assert np.array_equal(a[:b.size], b) and a.size - b.size <= 7, name
 
 
+def test_large_planes_use_worker_threads_and_still_match(orc):
+    """Above about half a million symbols per plane the histogram and the bit packing
+    run on several threads (chunk-wise first-occurrence lists merged in order, chunks
+    packed from their own bit offsets): the bytes must not change."""
+    rng = np.random.default_rng(11)
+    n = 3_300_001
+    s = (rng.geometric(0.25, n).astype(np.int32) - 2) * rng.choice(np.array([-1, 1], np.int32), n)
+    s[2_900_000:2_900_050] = np.arange(5000, 5050, dtype=np.int32)   # symbols whose first occurrence is late
+    s[-1] = -777
+    small = np.array([0, 64, 1, 1], np.int32)
+    data = jpeg_amd.bin_encode(s, small, s[:1_100_003], 64, 64)
+    assert data == orc.write_bin(s, small, s[:1_100_003], 64, 64)
+    dims, dec = jpeg_amd.bin_decode(data)
+    assert np.array_equal(dec[0][:n], s) and dec[0].size - n <= 7
+
+
 def test_very_long_codes_take_the_bitwise_path(orc):
     fib = [1, 1]
     while len(fib) < 62:   # depth 61 > 56 bits: beyond the flat code table
