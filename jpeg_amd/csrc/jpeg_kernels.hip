@@ -8,7 +8,8 @@
 //     cross-lane traffic, no transposes.
 //   * one WAVE owns a 512 x 16 pixel tile (32 MCUs: 128 Y + 32 Cb + 32 Cr
 //     blocks = three 64-lane transform rounds) and shares nothing with other
-//     waves: only wave-level LDS ordering, never a workgroup barrier.
+//     waves but the quantiser table (one barrier after its fill): from then on
+//     only wave-level LDS ordering.
 //   * global traffic is always lane-contiguous: 12 B/lane BGR rows (768 B per
 //     wave instruction) and 16 B/lane coefficient chunks (1 KiB per wave
 //     instruction, staged through LDS so that each block's 128 B stay whole).
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                 const int rp = t >> 1;
                 const int g = lane + 64 * (t & 1);
                 if (x0 + 4 * g < cols) {
-                    float ya[4], yb[4], sum_b[2] = {0.f, 0.f}, sum_r[2] = {0.f, 0.f};
+                    float ya[4], yb[4], sum_b[2], sum_r[2];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // The two rows of this column in one straight-line block, ONE tie test for
@@ -246,8 +247,13 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                                     jm_fwd_colour_fix(p[row][0], p[row][1], p[row][2], tie[row], uy[row], cb[row], cr[row]);
                         }
                         ya[j] = uy[0], yb[j] = uy[1];
-                        sum_b[j >> 1] += cb[0] + cb[1];
-                        sum_r[j >> 1] += cr[0] + cr[1];
+                        if (j & 1) { // second column of the quad
+                            sum_b[j >> 1] += cb[0] + cb[1];
+                            sum_r[j >> 1] += cr[0] + cr[1];
+                        } else {
+                            sum_b[j >> 1] = cb[0] + cb[1];
+                            sum_r[j >> 1] = cr[0] + cr[1];
+                        }
                     }
                     // bytes go to LDS one by one (the low byte of each magic float): byte stores
                     // ride the LDS queue, packing them first would cost ten VALU permutes
