@@ -144,6 +144,9 @@ int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride
 int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_luma[64], const int32_t q_chroma[64],
                              uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows, int *cols);
 void jpegamd_free(void *p);
+/* main.cpp:3-20, 51-80: the Annex-K base tables scaled for quality 1..100
+ * (row-major 8x8, clamped to 1..255); non-zero for a quality outside that range. */
+int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]);
 
 /* Times `iters` back-to-back launches of encode followed by decode on `stream`
  * with HIP events recorded on that same stream; writes the mean milliseconds

@@ -1,0 +1,252 @@
+// jpegamd_main: the GPU branch of the reference's command-line harness
+// (main.cpp:22-337) on top of libjpeg_amd.so.
+//
+//   echo image.ppm | jpegamd_main [-q N] [-o DIR]
+//
+// Same protocol as main.cpp: `-q N` (1..100, default 50, :24-47), the image
+// name is read from stdin after the "Enter the image name: " prompt (:84-85),
+// the compressed file goes to DIR/compressed_image_gpu_<q>.bin (:166) and the
+// report lines carry the reference's wording for its GPU leg (:49, :93, :123,
+// :150, :171, :191-194, :244, :264, :328-330).
+//
+// Differences, on purpose:
+//  * no OpenCV in this image: the input is a binary PPM (P6, maxval 255) and the
+//    reconstruction is written as DIR/decompress_image_gpu_<q>.ppm (main.cpp
+//    reads anything imread does and writes PNG, :300);
+//  * ensureMultipleOf16 (encode_decode.cpp:29-37) resizes with cv::INTER_AREA;
+//    here an image whose sides are not multiples of 16 is rejected;
+//  * only the GPU leg runs, so there are no CPU/OMP lines and no speed-up lines;
+//  * "Original size" is rows*cols*3 as in calculateCompressionStats
+//    (encode_decode.cpp:185-231), taken from the image in memory.
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "../../../include/jpeg_amd.h"
+}
+
+namespace {
+
+struct Image {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> bgr; // interleaved B,G,R like cv::Mat CV_8UC3
+};
+
+int ppm_token(std::istream &in)
+{
+    // header integers, skipping whitespace and '#' comments
+    for (;;) {
+        int c = in.peek();
+        if (c == '#') {
+            std::string skip;
+            std::getline(in, skip);
+        } else if (c == ' ' || c == '\t' || c == '\n' || c == '\r') {
+            in.get();
+        } else
+            break;
+    }
+    int v = -1;
+    in >> v;
+    if (!in || v < 0)
+        throw std::runtime_error("malformed PPM header");
+    return v;
+}
+
+Image read_ppm(const std::string &path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in)
+        throw std::runtime_error("Could not open or find the image"); // readImage, encode_decode.cpp:23
+    char magic[2] = {0, 0};
+    in.read(magic, 2);
+    if (magic[0] != 'P' || magic[1] != '6')
+        throw std::runtime_error("not a binary PPM (P6): " + path);
+    Image img;
+    img.cols = ppm_token(in);
+    img.rows = ppm_token(in);
+    const int maxval = ppm_token(in);
+    in.get(); // the single whitespace byte after maxval
+    if (maxval != 255 || img.rows <= 0 || img.cols <= 0)
+        throw std::runtime_error("PPM must have maxval 255 and positive size: " + path);
+    const size_t n = (size_t)img.rows * img.cols;
+    std::vector<uint8_t> rgb(n * 3);
+    in.read((char *)rgb.data(), (std::streamsize)rgb.size());
+    if ((size_t)in.gcount() != rgb.size())
+        throw std::runtime_error("PPM pixel data is truncated: " + path);
+    img.bgr.resize(n * 3);
+    for (size_t i = 0; i < n; ++i) {
+        img.bgr[3 * i + 0] = rgb[3 * i + 2];
+        img.bgr[3 * i + 1] = rgb[3 * i + 1];
+        img.bgr[3 * i + 2] = rgb[3 * i + 0];
+    }
+    return img;
+}
+
+void write_ppm(const std::string &path, const Image &img)
+{
+    std::ofstream out(path, std::ios::binary);
+    if (!out)
+        throw std::runtime_error("Cannot open file for writing: " + path);
+    out << "P6\n" << img.cols << " " << img.rows << "\n255\n";
+    const size_t n = (size_t)img.rows * img.cols;
+    std::vector<uint8_t> rgb(n * 3);
+    for (size_t i = 0; i < n; ++i) {
+        rgb[3 * i + 0] = img.bgr[3 * i + 2];
+        rgb[3 * i + 1] = img.bgr[3 * i + 1];
+        rgb[3 * i + 2] = img.bgr[3 * i + 0];
+    }
+    out.write((const char *)rgb.data(), (std::streamsize)rgb.size());
+}
+
+// calculateMSE (encode_decode.cpp:1386-1401): squared differences as float, summed
+// per channel in double, over total()*channels().
+double mean_squared_error(const Image &a, const Image &b)
+{
+    double sum[3] = {0, 0, 0};
+    const size_t n = (size_t)a.rows * a.cols;
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const float d = (float)std::abs((int)a.bgr[3 * i + c] - (int)b.bgr[3 * i + c]);
+            sum[c] += (double)(d * d);
+        }
+    return (sum[0] + sum[1] + sum[2]) / ((double)n * 3.0);
+}
+
+void check(int rc)
+{
+    if (rc)
+        throw std::runtime_error(jpegamd_last_error());
+}
+
+double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace
+
+int main(int argc, char *argv[])
+{
+    using std::cout;
+    using std::endl;
+    int quality = 50;
+    std::string out_dir = "output";
+    for (int i = 1; i < argc; ++i) {
+        const std::string arg = argv[i];
+        if (arg == "-q" && i + 1 < argc) {
+            try {
+                quality = std::stoi(argv[++i]);
+                if (quality < 1 || quality > 100)
+                    throw std::out_of_range("Quality must be between 1 and 100");
+            } catch (std::exception &e) {
+                std::cerr << "Invalid quality argument: " << e.what() << endl;
+                return 1;
+            }
+        } else if (arg == "-o" && i + 1 < argc) {
+            out_dir = argv[++i];
+        }
+    }
+    cout << "Using quality: " << quality << "%" << endl;
+
+    try {
+        int32_t q_luma[64], q_chroma[64];
+        check(jpegamd_quality_tables(quality, q_luma, q_chroma));
+
+        std::string image_name;
+        cout << "Enter the image name: ";
+        std::cin >> image_name;
+        const Image image = read_ppm(image_name);
+        if (image.rows % 16 || image.cols % 16)
+            throw std::runtime_error("image sides must be multiples of 16 (the reference resizes with OpenCV; "
+                                     "this harness does not)");
+        cout << "Image Dimensions: " << image.rows << " x " << image.cols << endl;
+        cout << "====================================================\n";
+
+        check(jpegamd_init(0));
+        {
+            // first use of the device (context, code object load) stays out of the timings,
+            // as the reference's CUDA context does after its CPU leg has run
+            uint8_t *warm = nullptr;
+            size_t warm_len = 0;
+            std::vector<uint8_t> tile(16 * 16 * 3, 128);
+            check(jpegamd_compress_image(tile.data(), 16, 16, 48, q_luma, q_chroma, &warm, &warm_len));
+            jpegamd_free(warm);
+        }
+
+        cout << "Compressed with GPU" << endl;
+        cout << "======================================\n";
+        uint8_t *bin = nullptr;
+        size_t bin_len = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        check(jpegamd_compress_image(image.bgr.data(), image.rows, image.cols, (size_t)image.cols * 3, q_luma,
+                                     q_chroma, &bin, &bin_len));
+        const double encode_ms = ms_since(t0);
+        cout << "Encoding time (GPU): " << encode_ms << " ms" << endl;
+        cout << "======================================\n\n";
+
+        const std::string bin_name = out_dir + "/compressed_image_gpu_" + std::to_string(quality) + ".bin";
+        {
+            std::ofstream f(bin_name, std::ios::binary);
+            if (!f)
+                throw std::runtime_error("Cannot open file for writing: " + bin_name);
+            f.write((const char *)bin, (std::streamsize)bin_len);
+        }
+        jpegamd_free(bin);
+        cout << "Compressed file (GPU) saved in: " << bin_name << endl;
+
+        // calculateCompressionStats: sizes from the image and from the file on disk
+        std::ifstream f(bin_name, std::ios::binary | std::ios::ate);
+        if (!f)
+            throw std::runtime_error("Cannot open the compressed file: " + bin_name);
+        const size_t compressed_size = (size_t)f.tellg();
+        const size_t original_size = (size_t)image.rows * image.cols * 3;
+        cout << "Original size (GPU): " << original_size << " bytes (" << original_size / 1024.0 << " KB)" << endl;
+        cout << "Compressed size (GPU): " << compressed_size << " bytes (" << compressed_size / 1024.0 << " KB)"
+             << endl;
+        cout << "Compression ratio (GPU): " << (compressed_size ? (double)original_size / compressed_size : 0.0)
+             << endl;
+        cout << "Percentage reduction (GPU): "
+             << (compressed_size ? (1.0 - (double)compressed_size / original_size) * 100 : 0.0) << "%" << endl;
+        cout << "======================================\n\n";
+
+        // back from the file, like loadEncodedData + mainDecode + upsampleChroma + YCbCr2RGB
+        std::vector<uint8_t> file(compressed_size);
+        f.seekg(0);
+        f.read((char *)file.data(), (std::streamsize)file.size());
+        cout << "Decompressed with GPU" << endl;
+        cout << "======================================\n";
+        Image rec;
+        t0 = std::chrono::steady_clock::now();
+        check(jpegamd_decompress_image(file.data(), file.size(), q_luma, q_chroma, nullptr, 0, 0, &rec.rows,
+                                       &rec.cols));
+        rec.bgr.resize((size_t)rec.rows * rec.cols * 3);
+        check(jpegamd_decompress_image(file.data(), file.size(), q_luma, q_chroma, rec.bgr.data(), rec.bgr.size(),
+                                       (size_t)rec.cols * 3, &rec.rows, &rec.cols));
+        const double decode_ms = ms_since(t0);
+        cout << "Decoding time (GPU): " << decode_ms << " ms" << endl;
+        cout << "======================================\n\n";
+
+        write_ppm(out_dir + "/decompress_image_gpu_" + std::to_string(quality) + ".ppm", rec);
+
+        if (rec.rows != image.rows || rec.cols != image.cols)
+            throw std::runtime_error("Images must have the same size and type for MSE calculation.");
+        const double mse = mean_squared_error(image, rec);
+        const double psnr = mse == 0 ? INFINITY : 10.0 * std::log10((255 * 255) / mse);
+        cout << "Image Metrics (GPU):" << endl;
+        cout << "  MSE: " << mse << endl;
+        cout << "  PSNR: " << psnr << " dB" << endl;
+        cout << "======================================\n\n";
+    } catch (std::exception &e) {
+        std::cerr << "Error: " << e.what() << endl;
+        return 1;
+    }
+    return 0;
+}

@@ -61,6 +61,29 @@ extern "C" {
 
 void jpegamd_free(void *p) { std::free(p); }
 
+int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64])
+{
+    // main.cpp:3-20 (base tables, ITU-T T.81 Annex K) and :51-80 (scaling)
+    static const uint8_t base_luma[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                                          14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                                          18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                                          49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+    static const uint8_t base_chroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                                            24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                            99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                            99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+    if (!q_luma || !q_chroma)
+        return jpegamd_fail("quality_tables: null pointer");
+    if (quality < 1 || quality > 100)
+        return jpegamd_fail("Quality must be between 1 and 100");
+    const int sf = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    for (int i = 0; i < 64; ++i) {
+        q_luma[i] = std::max(1, std::min(255, (base_luma[i] * sf + 50) / 100));
+        q_chroma[i] = std::max(1, std::min(255, (base_chroma[i] * sf + 50) / 100));
+    }
+    return 0;
+}
+
 int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
                            const int32_t q_chroma[64], uint8_t **bin, size_t *bin_len)
 {
