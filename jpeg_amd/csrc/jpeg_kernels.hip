@@ -475,15 +475,13 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
 // of lane l holds x = 4g + r for (s,u) = xl -- exactly the A-operand layout of
 // K-step r of pass two once the constant B operand is permuted the same way -- so
 // nothing moves between the passes.  Lane l ends up with the four coefficients
-// (s,u) = 4g + r, (b,v) = xl of its group: quantised and stored as int16 straight
-// to their zigzag slots.  The level shift is the accumulator's initial value.
+// (s,u) = 4g + r, (b,v) = xl of its group: quantised, staged in LDS at their zigzag
+// slots (32 blocks per round) and stored as 1 KiB wave-contiguous pieces.  The level
+// shift is the accumulator's initial value.
 // Numerics: an MFMA is a k-ordered fma chain, replayed on the host by
 // jm_mfma_fdct_block / jm_mfma_idct_block.
 // =============================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kYBytes = 16 * 512;                  // 16 luma rows of the tile
-constexpr int kWaveLdsM = kYBytes + kChromaBytes;   // 12288
 
 // natural (row-major) index -> zigzag scan position: the inverse of kZZ
 __device__ constexpr uint8_t kZZInv[64] = {
@@ -492,12 +490,22 @@ __device__ constexpr uint8_t kZZInv[64] = {
     10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
     21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
-// Sample (k, X) of a 16-row operand image, k = contraction index (luma: tile row;
-// chroma: 8*plane + row), stored so that lane (g, xl) of group c finds its four
-// K-steps k = 4t + g in one dword:  [X >> 4][k & 3][X & 15][k >> 2].
-__device__ __forceinline__ int operand_byte(int k, int X)
+// Operand images.  Sample (k, X) -- k = contraction index (luma: tile row; chroma:
+// 8*plane + row), X = column -- lives in group c = X >> 4, dword (k & 3) * 16 + (X & 15),
+// byte k >> 2: lane (g, xl) of the wave finds its four K-steps k = 4t + g of group c in
+// ONE dword, at lane-linear (conflict-free) addresses.  Groups are 68 dwords apart and
+// group c starts (c & 3) dwords in, so the colour stage's byte stores (lane = four pixel
+// columns, i.e. a quarter group) spread over 16 banks instead of 4.
+constexpr int kOpPitch = 68;
+constexpr int kYOpBytes = 32 * kOpPitch * 4;     // 8704: 16 luma rows x 512
+constexpr int kCOpBytes = 16 * kOpPitch * 4;     // 4352: (Cb, Cr) x 8 rows x 256
+constexpr int kStageHalf = 2048 + 64;            // 16 staged blocks of one strip / plane (+ 16 banks)
+constexpr int kWaveLdsM = kYOpBytes + kCOpBytes; // 13056; the staging area aliases the chroma operands
+static_assert(2 * kStageHalf <= kCOpBytes, "staging must fit in the chroma operand area");
+
+__device__ __forceinline__ constexpr int operand_group(int c) // byte offset of group c's dword 0
 {
-    return (((X >> 4) * 4 + (k & 3)) * 16 + (X & 15)) * 4 + (k >> 2);
+    return (c * kOpPitch + (c & 3)) * 4;
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -516,11 +524,17 @@ __device__ __forceinline__ void groups_fdct_quant(const uint32_t (&a4)[NG], cons
 {
     f32x4 d1[NG], d2[NG];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int i = 0; i < NG; ++i)
+        d1[i] = mfma4((float)((a4[i] >> 0) & 0xFFu), b1[0], c1);
 #pragma unroll
-        for (int i = 0; i < NG; ++i)
-            d1[i] = mfma4((float)((a4[i] >> (8 * t)) & 0xFFu), b1[t], t == 0 ? c1 : d1[i]);
-    }
+    for (int i = 0; i < NG; ++i)
+        d1[i] = mfma4((float)((a4[i] >> 8) & 0xFFu), b1[1], d1[i]);
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+        d1[i] = mfma4((float)((a4[i] >> 16) & 0xFFu), b1[2], d1[i]);
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+        d1[i] = mfma4((float)((a4[i] >> 24) & 0xFFu), b1[3], d1[i]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -535,6 +549,34 @@ __device__ __forceinline__ void groups_fdct_quant(const uint32_t (&a4)[NG], cons
             q[i][r] = jm_fma(x, qm[r], JM_MAGIC);       // roundf(c / Q), :306 (see jm_quantise_block)
         }
     }
+}
+
+// One round = 8 groups = 16 block columns of both strips (luma) or both planes (chroma):
+// transform, quantise, stage the 32 blocks in zigzag order (2 halves x 16 blocks x 128 B)
+// and store them as four 1 KiB wave-contiguous pieces.  n_ok: blocks of this round's run
+// that lie inside the plane.
+__device__ __forceinline__ void mfma_round(const uint32_t (&a4)[8], const float (&b1)[4], const float (&b2)[4],
+                                           f32x4 c1, const float (&qm)[4], const int (&zoff)[4],
+                                           uint8_t *stage, int lane, uint8_t *dst0, uint8_t *dst1, int n_ok)
+{
+    float q[8][4];
+    groups_fdct_quant<8>(a4, b1, b2, c1, qm, q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<uint16_t *>(stage + zoff[r] + i * 256) = (uint16_t)jm_bits(q[i][r]);
+    }
+    wave_lds_fence();
+    const int blk = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if ((i & 1) * 8 + blk < n_ok) {
+            uint4 d = *reinterpret_cast<const uint4 *>(stage + (i >> 1) * kStageHalf + (i & 1) * 1024 + lane * 16);
+            *reinterpret_cast<uint4 *>(((i >> 1) ? dst1 : dst0) + (i & 1) * 1024 + lane * 16) = d;
+        }
+    }
+    wave_lds_fence(); // staged blocks are read (in-order LDS) before the next round overwrites them
 }
 
 __global__ __launch_bounds__(256, 3) void encode_image_mfma_kernel(
@@ -554,71 +596,92 @@ __global__ __launch_bounds__(256, 3) void encode_image_mfma_kernel(
         return; // whole wave leaves together; nothing else is shared between waves
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     uint8_t *ybuf = lds + wave * kWaveLdsM; // luma operand image, 16 rows x 512
-    uint8_t *cbuf = ybuf + kYBytes;         // chroma operand image, (Cb, Cr) x 8 rows x 256
+    uint8_t *cbuf = ybuf + kYOpBytes;       // chroma operand image, (Cb, Cr) x 8 rows x 256; later the staging area
     const int x0 = tx * kWaveTileW;
     const int bw_y = cols >> 3, bw_c = cols >> 4;
 
-    // ---- colour + 4:2:0 for the 16 tile rows (same task scheme as encode_image_kernel) ----
+    // ---- colour + 4:2:0 for the 16 tile rows: the task scheme of encode_image_kernel ------
+    // (task T covers tile rows 2*(T>>1), +1 and pixel group lane + 64*(T&1); four tasks of
+    // register-resident BGR rows are converted while the next four are in flight)
+    constexpr int kRing = 4;
     auto task_load = [&](int T, U3 &a, U3 &b) {
-        const int t = T & 7;
-        const int row = ty * 16 + (T >> 3) * 8 + 2 * (t >> 1);
-        const int x = x0 + 4 * (lane + 64 * (t & 1));
-        if (x < cols) {
-            const uint8_t *p = bgr + (size_t)row * stride + (size_t)x * 3;
-            a = *reinterpret_cast<const U3 *>(p);
-            b = *reinterpret_cast<const U3 *>(p + stride);
-        }
+        T = T < 15 ? T : 15;
+        const int row = ty * 16 + 2 * (T >> 1);
+        int x = x0 + 4 * (lane + 64 * (T & 1));
+        x = x < cols - 4 ? x : cols - 4;
+        const uint8_t *p = bgr + (size_t)row * stride + (size_t)x * 3;
+        a = *reinterpret_cast<const U3 *>(p);
+        b = *reinterpret_cast<const U3 *>(p + stride);
     };
-    U3 cur_a = {0, 0, 0}, cur_b = {0, 0, 0}, nxt_a = {0, 0, 0}, nxt_b = {0, 0, 0};
-    task_load(0, cur_a, cur_b);
-    task_load(1, nxt_a, nxt_b);
+    U3 ring_a[kRing], ring_b[kRing];
+#pragma unroll
+    for (int i = 0; i < kRing; ++i)
+        task_load(i, ring_a[i], ring_b[i]);
+    // this lane's quarter group (luma: columns 4G .. 4G+3) / eighth group (chroma: 2G, 2G+1)
+    const int ylane = operand_group(lane >> 2) + 16 * (lane & 3);
+    const int clane = operand_group(lane >> 3) + 8 * (lane & 7);
 #pragma unroll 1
-    for (int T = 0; T < 16; ++T) {
-        U3 far_a = {0, 0, 0}, far_b = {0, 0, 0};
-        if (T + 2 < 16)
-            task_load(T + 2, far_a, far_b);
-        const int it = T >> 3, rp = (T & 7) >> 1;
-        const int G = lane + 64 * (T & 1); // pixel group: columns 4G .. 4G+3 of the tile
-        if (x0 + 4 * G < cols) {
-            float ya[4], yb[4], sum_b[2] = {0.f, 0.f}, sum_r[2] = {0.f, 0.f};
+    for (int T0 = 0; T0 < 16; T0 += kRing) {
+        U3 next_a[kRing], next_b[kRing];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int i = 0; i < kRing; ++i)
+            task_load(T0 + kRing + i, next_a[i], next_b[i]);
+        // rows T0 + (slot & 2), +1: k & 3 = (slot & 2), +1 and k >> 2 = T0 >> 2;
+        // chroma row kc = T0/2 + (slot >> 1): kc & 3 = (T0/2 & 2) + (slot >> 1), kc >> 2 = T0 >> 3
+        uint8_t *yq = ybuf + ylane + (T0 >> 2);
+        uint8_t *cq = cbuf + clane + ((T0 >> 1) & 2) * 64 + (T0 >> 3);
 #pragma unroll
-                for (int row = 0; row < 2; ++row) {
-                    const U3 &px = row ? cur_b : cur_a;
-                    float uy, cb, cr;
-                    JmFwdTies tie;
-                    const float p0 = (float)u3_byte(px, 3 * j), p1 = (float)u3_byte(px, 3 * j + 1),
-                                p2 = (float)u3_byte(px, 3 * j + 2);
-                    jm_fwd_colour_fast(p0, p1, p2, uy, cb, cr, tie);
-                    if (__builtin_expect(jm_fwd_any_tie(tie), 0)) // an exact x.5 somewhere: ask the doubles
-                        jm_fwd_colour_fix(p0, p1, p2, tie, uy, cb, cr);
-                    (row ? yb : ya)[j] = uy;
-                    sum_b[j >> 1] += cb;
-                    sum_r[j >> 1] += cr;
+        for (int slot = 0; slot < kRing; ++slot) {
+            const int half = slot & 1; // pixel groups 64 .. 127: 16 luma / 8 chroma operand groups further on
+            const int g = lane + 64 * half;
+            if (x0 + 4 * g < cols) {
+                float ya[4], yb[4], sum_b[2], sum_r[2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float uy[2], cb[2], cr[2], p[2][3];
+                    JmFwdTies tie[2];
+#pragma unroll
+                    for (int row = 0; row < 2; ++row) {
+                        const U3 &px = row ? ring_b[slot] : ring_a[slot];
+                        p[row][0] = (float)u3_byte(px, 3 * j), p[row][1] = (float)u3_byte(px, 3 * j + 1);
+                        p[row][2] = (float)u3_byte(px, 3 * j + 2);
+                        jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
+                    }
+                    const uint32_t any = jm_bits(tie[0].ty) | jm_bits(tie[0].tb) | jm_bits(tie[0].tr) |
+                                         jm_bits(tie[1].ty) | jm_bits(tie[1].tb) | jm_bits(tie[1].tr);
+                    if (__builtin_expect((int32_t)any < 0, 0)) { // an exact x.5 somewhere: ask the doubles
+#pragma unroll
+                        for (int row = 0; row < 2; ++row)
+                            if (jm_fwd_any_tie(tie[row]))
+                                jm_fwd_colour_fix(p[row][0], p[row][1], p[row][2], tie[row], uy[row], cb[row], cr[row]);
+                    }
+                    ya[j] = uy[0], yb[j] = uy[1];
+                    if (j & 1) {
+                        sum_b[j >> 1] += cb[0] + cb[1];
+                        sum_r[j >> 1] += cr[0] + cr[1];
+                    } else {
+                        sum_b[j >> 1] = cb[0] + cb[1];
+                        sum_r[j >> 1] = cr[0] + cr[1];
+                    }
+                }
+                uint8_t *yp = yq + half * operand_group(16) + (slot & 2) * 64;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    yp[4 * j] = (uint8_t)jm_bits(ya[j]);
+                    yp[64 + 4 * j] = (uint8_t)jm_bits(yb[j]);
+                }
+                // chromaSubsampling: truncating mean of the quad (:139-149); Cr is 8 contraction steps on
+                uint8_t *cp = cq + half * operand_group(8) + (slot >> 1) * 64;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    cp[4 * jj] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[jj]));
+                    cp[4 * jj + 2] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_r[jj]));
                 }
             }
-            // luma bytes (the low byte of each magic float) into the operand image
-            const int R0 = 8 * it + 2 * rp;
-            uint8_t *yp = ybuf + operand_byte(0, 4 * G); // + (R & 3) * 64 + (R >> 2) + 4 j
-            const int o0 = (R0 & 3) * 64 + (R0 >> 2), o1 = ((R0 + 1) & 3) * 64 + ((R0 + 1) >> 2);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                yp[o0 + 4 * j] = (uint8_t)jm_bits(ya[j]);
-                yp[o1 + 4 * j] = (uint8_t)jm_bits(yb[j]);
-            }
-            // chromaSubsampling: truncating mean of the quad (:139-149); chroma row 4 it + rp
-            const int kc = 4 * it + rp; // contraction index of Cb; Cr is kc + 8
-            uint8_t *cp = cbuf + operand_byte(0, 2 * G);
-            const int ob = (kc & 3) * 64 + (kc >> 2), orr = ob + 2; // (kc + 8) >> 2 = (kc >> 2) + 2
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                cp[ob + 4 * jj] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[jj]));
-                cp[orr + 4 * jj] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_r[jj]));
-            }
         }
-        cur_a = nxt_a, cur_b = nxt_b;
-        nxt_a = far_a, nxt_b = far_b;
+#pragma unroll
+        for (int i = 0; i < kRing; ++i)
+            ring_a[i] = next_a[i], ring_b[i] = next_b[i];
     }
     wave_lds_fence();
 
@@ -634,62 +697,51 @@ __global__ __launch_bounds__(256, 3) void encode_image_mfma_kernel(
     }
     const float lv = (xl & 7) == 0 ? JM_LEVEL_DC : 0.0f; // recenterAroundZero (:289-298) reaches u = 0 only
     const f32x4 c1 = {lv, lv, lv, lv};
-    // this lane's four outputs of a group: (s, u) = 4g + r, (b, v) = xl
+    // this lane's four outputs of a group: (s, u) = 4g + r, (b, v) = xl -> half s, block b of the
+    // group's two, zigzag slot of (u, v)
     float qml[4], qmc[4];
-    int zz[4];
+    int zoff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int nat = (4 * (g & 1) + r) * 8 + (xl & 7);
         qml[r] = qtab[nat];
         qmc[r] = qtab[64 + nat];
-        zz[r] = kZZInv[nat];
+        zoff[r] = (g >> 1) * kStageHalf + (xl >> 3) * 128 + 2 * kZZInv[nat];
     }
-    constexpr int NG = 4; // groups in flight
+    uint8_t *stage = cbuf;
     {
-        // luma: 2 x 2 blocks per group; strip s = g >> 1, block column 2c + (xl >> 3)
-        const int n_groups = min(32, (cols - x0) >> 4);
-        int16_t *dst = coef_y + ((size_t)(ty * 2 + (g >> 1)) * bw_y + tx * 64 + (xl >> 3)) * 64;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(ybuf) + g * 16 + xl;
-#pragma unroll 1
-        for (int c0 = 0; c0 < n_groups; c0 += NG) {
-            uint32_t a4[NG];
-            float q[NG][4];
+        // chroma first: all 16 operand dwords go to registers, which frees their area for staging
+        uint32_t ca[16];
 #pragma unroll
-            for (int i = 0; i < NG; ++i)
-                a4[i] = src[(c0 + i) * 64]; // groups beyond n_groups read stale LDS: finite bytes, never stored
-            groups_fdct_quant<NG>(a4, b1, b2, c1, qml, q);
+        for (int i = 0; i < 16; ++i)
+            ca[i] = *reinterpret_cast<const uint32_t *>(cbuf + operand_group(i) + lane * 4);
+        wave_lds_fence();
+        const int n_ok = min(32, bw_c - tx * 32);
+        uint8_t *pb = reinterpret_cast<uint8_t *>(coef_cb + ((size_t)ty * bw_c + tx * 32) * 64);
+        uint8_t *pr = reinterpret_cast<uint8_t *>(coef_cr + ((size_t)ty * bw_c + tx * 32) * 64);
 #pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                if (c0 + i < n_groups) {
+        for (int f = 0; f < 2; ++f) {
+            uint32_t a4[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dst[(c0 + i) * 128 + zz[r]] = (int16_t)(jm_bits(q[i][r]) & 0xFFFFu);
-                }
-            }
+            for (int i = 0; i < 8; ++i)
+                a4[i] = ca[8 * f + i];
+            mfma_round(a4, b1, b2, c1, qmc, zoff, stage, lane, pb + f * 2048, pr + f * 2048, n_ok - 16 * f);
         }
     }
     {
-        // chroma: plane p = g >> 1 (Cb, Cr), 2 blocks per group
-        const int n_blocks = min(32, bw_c - tx * 32);
-        const int n_groups = (n_blocks + 1) >> 1;
-        int16_t *dst = ((g >> 1) ? coef_cr : coef_cb) + ((size_t)ty * bw_c + tx * 32 + (xl >> 3)) * 64;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(cbuf) + g * 16 + xl;
+        // luma: strip s = block row of the tile
+        const int n_ok = min(64, bw_y - tx * 64);
+        uint8_t *p0 = reinterpret_cast<uint8_t *>(coef_y + ((size_t)(ty * 2) * bw_y + tx * 64) * 64);
+        uint8_t *p1 = p0 + (size_t)bw_y * 128;
 #pragma unroll 1
-        for (int c0 = 0; c0 < n_groups; c0 += NG) {
-            uint32_t a4[NG];
-            float q[NG][4];
+        for (int f = 0; f < 4; ++f) {
+            if (16 * f >= n_ok)
+                break; // groups beyond the image were never written by the colour stage
+            uint32_t a4[8];
 #pragma unroll
-            for (int i = 0; i < NG; ++i)
-                a4[i] = src[(c0 + i) * 64];
-            groups_fdct_quant<NG>(a4, b1, b2, c1, qmc, q);
-#pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                if (2 * (c0 + i) + (xl >> 3) < n_blocks) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dst[(c0 + i) * 128 + zz[r]] = (int16_t)(jm_bits(q[i][r]) & 0xFFFFu);
-                }
-            }
+            for (int i = 0; i < 8; ++i)
+                a4[i] = *reinterpret_cast<const uint32_t *>(ybuf + f * operand_group(8) + operand_group(i) + lane * 4);
+            mfma_round(a4, b1, b2, c1, qml, zoff, stage, lane, p0 + f * 2048, p1 + f * 2048, n_ok - 16 * f);
         }
     }
 }
@@ -877,7 +929,9 @@ int check_image(const void *p, int rows, int cols, size_t stride, const char *wh
 
 // JPEGAMD_TRANSFORM=mfma runs the forward transform of the fused encoder on the matrix
 // cores (encode_image_mfma_kernel).  Measured slower than the VALU kernel on gfx950
-// (DESIGN.md 3): f32 MFMA does not overlap with VALU work there.  Read on every call.
+// (148 vs 116 us at 8192^2): v_mfma_f32_*_f32 executes on the VALU's own
+// lanes there (tools/mfma_overlap_ubench.hip), so it adds to the VALU time instead of
+// hiding behind it.  Read on every call.
 bool use_matrix_cores()
 {
     const char *e = getenv("JPEGAMD_TRANSFORM");

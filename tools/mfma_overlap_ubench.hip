@@ -1,0 +1,77 @@
+// Developer microbenchmark: does v_mfma_f32_16x16x4_f32 (and the bf16 form) run beside
+// VALU fma work of ANOTHER wave on the same SIMD?  512-thread workgroups put two waves on
+// each SIMD: waves 0-3 take role A, waves 4-7 role B.  If the pipes are separate,
+// time(mfma | valu) ~ max of the two alone; if they share the lanes, ~ the sum.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// role: 0 idle, 1 f32 mfma, 2 valu fma, 3 bf16 mfma
+__global__ __launch_bounds__(512) void k(float *out, int iters, int role_a, int role_b)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave < 4 ? role_a : role_b;
+    float x = threadIdx.x * 1e-3f;
+    f32x4 acc[4] = {{x, x, x, x}, {x, x, x, x}, {x, x, x, x}, {x, x, x, x}};
+    float v[8] = {x, x + 1, x + 2, x + 3, x + 4, x + 5, x + 6, x + 7};
+    if (role == 1) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, 0.5f, acc[c], 0, 0, 0);
+        }
+    } else if (role == 3) {
+        bf16x8 a = {1, 2, 3, 4, 5, 6, 7, 8};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, acc[c], 0, 0, 0);
+        }
+    } else if (role == 2) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(x), "v"(0.25f));
+        }
+    }
+    float s = 0;
+    for (int c = 0; c < 4; ++c)
+        s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    for (int c = 0; c < 8; ++c)
+        s += v[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+static float run(float *d, int iters, int a, int b)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    k<<<256, 512>>>(d, iters, a, b); // one workgroup per CU
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<<<256, 512>>>(d, iters, a, b);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f;
+}
+
+int main()
+{
+    float *d;
+    hipMalloc(&d, 256 * 512 * sizeof(float));
+    const int iters = 4000; // 64 k mfma (16 per iter) or 512 k fma (128 per iter) per wave
+    const char *names[] = {"idle", "mfma_f32", "valu_fma", "mfma_bf16"};
+    const int cases[][2] = {{1, 0}, {0, 2}, {1, 2}, {2, 2}, {1, 1}, {3, 0}, {3, 2}, {3, 3}};
+    for (auto &c : cases)
+        printf("%-10s | %-10s : %8.1f us\n", names[c[0]], names[c[1]], run(d, iters, c[0], c[1]));
+    return 0;
+}
