@@ -238,9 +238,9 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                             p[row][2] = (float)u3_byte(px, 3 * j + 2);
                             jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
                         }
-                        const uint32_t any = jm_bits(tie[0].ty) | jm_bits(tie[0].tb) | jm_bits(tie[0].tr) |
-                                             jm_bits(tie[1].ty) | jm_bits(tie[1].tb) | jm_bits(tie[1].tr);
-                        if (__builtin_expect((int32_t)any < 0, 0)) { // an exact x.5 somewhere: ask the doubles
+                        const float worst_a = jm_min2(jm_min3(tie[0].ry, tie[0].rr, tie[1].ry), tie[1].rr);
+                        const float worst_b = jm_min2(tie[0].rb, tie[1].rb);
+                        if (__builtin_expect(worst_a < JM_TIE_A || worst_b < JM_TIE_B, 0)) { // ask the doubles
 #pragma unroll
                             for (int row = 0; row < 2; ++row)
                                 if (jm_fwd_any_tie(tie[row]))
@@ -647,9 +647,9 @@ __global__ __launch_bounds__(256, 3) void encode_image_mfma_kernel(
                         p[row][2] = (float)u3_byte(px, 3 * j + 2);
                         jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
                     }
-                    const uint32_t any = jm_bits(tie[0].ty) | jm_bits(tie[0].tb) | jm_bits(tie[0].tr) |
-                                         jm_bits(tie[1].ty) | jm_bits(tie[1].tb) | jm_bits(tie[1].tr);
-                    if (__builtin_expect((int32_t)any < 0, 0)) { // an exact x.5 somewhere: ask the doubles
+                    const float worst_a = jm_min2(jm_min3(tie[0].ry, tie[0].rr, tie[1].ry), tie[1].rr);
+                    const float worst_b = jm_min2(tie[0].rb, tie[1].rb);
+                    if (__builtin_expect(worst_a < JM_TIE_A || worst_b < JM_TIE_B, 0)) { // ask the doubles
 #pragma unroll
                         for (int row = 0; row < 2; ++row)
                             if (jm_fwd_any_tie(tie[row]))

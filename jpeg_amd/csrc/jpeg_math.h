@@ -452,41 +452,75 @@ JM_HD uint32_t jm_pack4_u8(float a, float b, float c, float d)
 // Forward: the same decision as jm_fwd_colour (exact rational rounding, with
 // exact x.5 ties handed to the reference's double sequence), but the common
 // case runs on float fma/add only.
-//   Y      float chain of value + 5e-4 (error < 5e-5; the rational values are 1e-3 apart).
+//   Y      float chain of value + 6e-5 (error < 4.6e-5; the rational values are 1e-3 apart).
 //   Cb, Cr centred chains  s = value - 128 + 5e-5  (error < 2e-5; the rational
 //          values are 1e-4 apart).  The bias makes the magic add round exact ties
 //          UP, which is what round() does unless the double sequence lands below
 //          the tie; c = rounded - 128 comes back as an exact float for the quad
 //          sums, and the byte (with the 256 -> 0 wrap of static_cast<uchar>,
 //          :67-70) sits in the low 8 bits of s + (MAGIC + 128).
-// A channel is an exact-tie candidate when its residual says "x.5": `t*` collect
-// that as a sign bit.
+// Only triples whose double sequence lands BELOW an exact tie need anything else than
+// the biased chains (which round ties up): 3464 Y, 34 Cb and 4186 Cr triples of 2^24,
+// plus the two wraps Cb(0,0,255) = Cr(255,0,0) = 256 -> 0.  Candidates are found from
+// the rounding residuals r = s - round(s) (a tie sits at -0.5 + bias):
+//   Y, Cr  candidate iff r < JM_TIE_A (every exact tie).
+//   Cb     all 34 triples have Cb <= 64 and the wrap has Cb = 256, so the test value
+//          r - 1.5e-4 |cb| is compared with JM_TIE_B: exact ties with |Cb - 128| >= 64
+//          (plus, harmlessly, near-ties of more saturated pixels).  Every Cb tie has
+//          R == G, which photographs have in ~0.5 % of their pixels: without this filter
+//          they were 40 % of all candidates.
+// Smaller = more suspicious, so a wave takes the MINIMUM over a few pixels and compares once.
+JM_HD float jm_abs(float x) { return __builtin_fabsf(x); }
+// min of three / two floats, none of them NaN (v_min3_f32 without the canonicalising
+// extras fminf would get)
+JM_HD float jm_min3(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    float m = a < b ? a : b;
+    return m < c ? m : c;
+#endif
+}
+JM_HD float jm_min2(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a < b ? a : b;
+#endif
+}
 struct JmFwdTies {
     float sy, sb, sr; // the unrounded float values (Y; Cb, Cr centred and biased)
-    float ty, tb, tr; // sign bit set: that channel is an exact-tie candidate
+    float ry, rb, rr; // test values: candidate iff ry, rr < JM_TIE_A or rb < JM_TIE_B
 };
 #define JM_CHROMA_BIAS 5.0e-5f
-
-#define JM_LUMA_BIAS 5.0e-4f
+#define JM_LUMA_BIAS 6.0e-5f
+#define JM_TIE_A (-0.49988f)
+#define JM_CB_SLOPE 1.5e-4f
+#define JM_TIE_B (-0.5095f) // -0.49995 - 64 * JM_CB_SLOPE = -0.50955 fires, 63 -> -0.5094 does not
 
 JM_HD void jm_fwd_colour_fast(float p0, float p1, float p2, float &uy, float &cb, float &cr, JmFwdTies &t)
 {
-    // Y: value + 5e-4 (the rational values are 1e-3 apart, the chain's error is below
-    // 5e-5), so exact ties round UP here too and show as a residual of -0.5 + 5e-4
+    // Y: value + 6e-5 (the chain's error is below 4.6e-5, the rational values are 1e-3 apart)
     t.sy = jm_fma(p2, 0.114f, jm_fma(p1, 0.587f, jm_fma(p0, 0.299f, JM_LUMA_BIAS)));
     uy = t.sy + JM_MAGIC;
-    t.ty = (t.sy - (uy - JM_MAGIC)) + 0.499f;
+    t.ry = t.sy - (uy - JM_MAGIC);
     t.sb = jm_fma(p2, 0.5f, jm_fma(p1, -0.3313f, jm_fma(p0, -0.1687f, JM_CHROMA_BIAS)));
     cb = (t.sb + JM_MAGIC) - JM_MAGIC;
-    t.tb = (t.sb - cb) + 0.4999f; // residual of a tie is -0.5 + bias
+    t.rb = jm_fma(jm_abs(cb), -JM_CB_SLOPE, t.sb - cb);
     t.sr = jm_fma(p2, -0.0813f, jm_fma(p1, -0.4187f, jm_fma(p0, 0.5f, JM_CHROMA_BIAS)));
     cr = (t.sr + JM_MAGIC) - JM_MAGIC;
-    t.tr = (t.sr - cr) + 0.4999f;
+    t.rr = t.sr - cr;
 }
 
 JM_HD bool jm_fwd_any_tie(const JmFwdTies &t)
 {
-    return (int32_t)(jm_bits(t.ty) | jm_bits(t.tb) | jm_bits(t.tr)) < 0;
+    return t.ry < JM_TIE_A || t.rr < JM_TIE_A || t.rb < JM_TIE_B;
 }
 
 // Exact ties: the value is k + 0.5 as a rational; the reference's double sequence
@@ -501,14 +535,14 @@ JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, f
     asm("" : "+v"(p0), "+v"(p1), "+v"(p2));
 #endif
     const double d0 = (double)p0, d1 = (double)p1, d2 = (double)p2;
-    if ((int32_t)jm_bits(t.ty) < 0) {
+    if (t.ry < JM_TIE_A) {
         double v = 0.299 * d0; // 0.0 + x is exact
         v = v + 0.587 * d1;
         v = v + 0.114 * d2;
         float k = ((t.sy - 0.5f) + JM_MAGIC) - JM_MAGIC;
         uy = (v >= (double)k + 0.5 ? k + 1.0f : k) + JM_MAGIC;
     }
-    if ((int32_t)jm_bits(t.tb) < 0) {
+    if (t.rb < JM_TIE_B) {
         double v = 128.0 + -0.1687 * d0;
         v = v + -0.3313 * d1;
         v = v + 0.5 * d2;
@@ -516,7 +550,7 @@ JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, f
         cb = v >= (double)k + 128.5 ? k + 1.0f : k;
         cb = cb == 128.0f ? -128.0f : cb;
     }
-    if ((int32_t)jm_bits(t.tr) < 0) {
+    if (t.rr < JM_TIE_A) {
         double v = 128.0 + 0.5 * d0;
         v = v + -0.4187 * d1;
         v = v + -0.0813 * d2;
