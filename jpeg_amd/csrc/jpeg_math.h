@@ -245,6 +245,17 @@ JM_HD void jm_idct8(float &x0, float &x1, float &x2, float &x3,
 // with one f32 rounding per product (cdna_hip_programming.md, FP32-input MFMA), so the
 // kernels' matrix-core transform is a plain fma chain the host can replay bit for bit.
 // The basis  m(u, n) = (c_u / 2) cos((2n+1) u pi / 16)  is rounded to float once.
+// the same basis as a double (compile-time tables)
+constexpr double jm_dct_basis_f64(int u, int n)
+{
+    int a = ((2 * n + 1) * u) & 31;
+    a = a > 16 ? 32 - a : a;
+    const bool neg = a > 8;
+    a = neg ? 16 - a : a;
+    const double m = (a == 0 || a == 4) ? JM_A0 : a == 1 ? JM_C1 : a == 2 ? JM_C2 : a == 3 ? JM_C3
+                     : a == 5 ? JM_C5 : a == 6 ? JM_C6 : JM_C7;
+    return u == 0 ? JM_A0 : neg ? -m : m;
+}
 JM_HD float jm_dct_basis(int u, int n, double scale)
 {
     // (2n+1) u pi/16 folded into the first octant: only JM_A0 and JM_C1..JM_C7 occur

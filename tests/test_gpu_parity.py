@@ -148,6 +148,25 @@ def test_matrix_core_encoder_variant(gpu, orc, model, monkeypatch):
             assert np.array_equal(g, m), "matrix-core kernel differs from its host replay"
 
 
+def test_f16_matrix_pipe_encoder_variant(gpu, orc, lena_bgr, monkeypatch):
+    """JPEGAMD_TRANSFORM=xdl: the opt-in encoder whose ROW pass runs as v_mfma_f32_16x16x32_f16
+    (pixels are exact in f16, each constant is three f16 terms).  The accumulation order inside
+    a 16-bit MFMA is undocumented, so there is no bit-exact host replay: the oracle's bar
+    (+-1 LSB, <= COEF_PPM) is the test, on synthetic images, ragged sizes and Lena."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    monkeypatch.setenv("JPEGAMD_TRANSFORM", "xdl")
+    cases = [(synth_image(r, c, seed, kind).numpy(), qf) for kind, seed, r, c, qf in
+             (("photo", 21, 64, 1040, 50), ("noise", 22, 48, 528, 90), ("photo", 23, 32, 16, 100),
+              ("noise", 24, 16, 2064, 10))]
+    cases += [(lena_bgr, 50), (lena_bgr, 95)]
+    for bgr, qf in cases:
+        qy, qc = jpeg_amd.quality_tables(qf)
+        coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)]
+        for g, w, n in zip(coefs, orc.encode_image(bgr, qy, qc), "Y Cb Cr".split()):
+            _check_coef(g, w, n)
+
+
 def test_colour_wrap_quirk(gpu, orc):
     """BGR(0,0,255) -> Cb = 256 -> 0 and BGR(255,0,0) -> Cr = 256 -> 0 (encode_decode.cpp:67-70)."""
     import jpeg_amd

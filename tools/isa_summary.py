@@ -4,7 +4,7 @@ import sys
 from collections import Counter
 
 s = open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/jpeg_kernels.s").read()
-for name in ("encode_image_mfma_kernel", "encode_image_kernel", "decode_image_kernel"):
+for name in ("encode_image_xdl_kernel", "encode_image_mfma_kernel", "encode_image_kernel", "decode_image_kernel"):
     sym = re.search(r"^(_ZN\S*\d+" + name + r"E\S*):", s, re.M).group(1)
     blk = re.search(r"\.amdhsa_kernel " + re.escape(sym) + r".*?\.end_amdhsa_kernel", s, re.S).group(0)
     meta = {k: re.search(k + r"\s+(\S+)", blk).group(1) for k in

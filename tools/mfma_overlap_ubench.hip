@@ -7,11 +7,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-// role: 0 idle, 1 f32 mfma, 2 valu fma, 3 bf16 mfma
-__global__ __launch_bounds__(512) void k(float *out, int iters, int role_a, int role_b)
+// role: 0 idle, 1 f32 mfma, 2 valu fma, 3 bf16 mfma (-1: wave absent)
+__global__ __launch_bounds__(768) void k(float *out, int iters, int role_a, int role_b, int role_c)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave < 4 ? role_a : role_b;
+    const int role = wave < 4 ? role_a : wave < 8 ? role_b : role_c;
     float x = threadIdx.x * 1e-3f;
     f32x4 acc[4] = {{x, x, x, x}, {x, x, x, x}, {x, x, x, x}, {x, x, x, x}};
     float v[8] = {x, x + 1, x + 2, x + 3, x + 4, x + 5, x + 6, x + 7};
@@ -49,14 +49,15 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, int role_a, int 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-static float run(float *d, int iters, int a, int b)
+static float run(float *d, int iters, int a, int b, int c = -1)
 {
+    const int threads = c < 0 ? 512 : 768; // two or three waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    k<<<256, 512>>>(d, iters, a, b); // one workgroup per CU
+    k<<<256, threads>>>(d, iters, a, b, c); // one workgroup per CU
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<<<256, 512>>>(d, iters, a, b);
+    k<<<256, threads>>>(d, iters, a, b, c);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -67,11 +68,15 @@ static float run(float *d, int iters, int a, int b)
 int main()
 {
     float *d;
-    hipMalloc(&d, 256 * 512 * sizeof(float));
+    hipMalloc(&d, 256 * 768 * sizeof(float));
     const int iters = 4000; // 64 k mfma (16 per iter) or 512 k fma (128 per iter) per wave
     const char *names[] = {"idle", "mfma_f32", "valu_fma", "mfma_bf16"};
     const int cases[][2] = {{1, 0}, {0, 2}, {1, 2}, {2, 2}, {1, 1}, {3, 0}, {3, 2}, {3, 3}};
     for (auto &c : cases)
         printf("%-10s | %-10s : %8.1f us\n", names[c[0]], names[c[1]], run(d, iters, c[0], c[1]));
+    // three waves per SIMD: is a third, matrix-only wave free when two VALU waves already fill the issue port?
+    const int cases3[][3] = {{2, 2, 0}, {2, 2, 3}, {2, 2, 1}, {2, 2, 2}};
+    for (auto &c : cases3)
+        printf("%-10s | %-10s | %-10s : %8.1f us\n", names[c[0]], names[c[1]], names[c[2]], run(d, iters, c[0], c[1], c[2]));
     return 0;
 }
