@@ -94,3 +94,79 @@ def test_batch_of_independent_images(gpu, orc):
     want = orc.encode_image(imgs[0].cpu().numpy(), qy, qc)
     for g, w, n in zip(alone[0], want, "Y Cb Cr".split()):
         _check_coef(g.cpu().numpy(), w, n)
+
+
+def _strip_parity(orc, bgr, coefs, rec, qy, qc, mcu_rows, what):
+    """every 16x16 MCU is independent: sampled MCU-row strips of a full-size image against
+    the oracle (coefficients and decoded pixels)"""
+    rows, cols = bgr.shape[:2]
+    bw, bwc = cols // 8, cols // 16
+    cy, cb, cr = coefs
+    for my in mcu_rows:
+        strip = bgr[my * 16:(my + 1) * 16].cpu().numpy()
+        wy, wcb, wcr = orc.encode_image(strip, qy, qc)
+        _check_coef(cy[my * 2 * bw:(my * 2 + 2) * bw].cpu().numpy(), wy, f"{what} strip {my} Y")
+        _check_coef(cb[my * bwc:(my + 1) * bwc].cpu().numpy(), wcb, f"{what} strip {my} Cb")
+        _check_coef(cr[my * bwc:(my + 1) * bwc].cpu().numpy(), wcr, f"{what} strip {my} Cr")
+        _check_px(rec[my * 16:(my + 1) * 16].cpu().numpy(), orc.decode_image(wy, wcb, wcr, 16, cols, qy, qc),
+                  f"{what} strip {my} pixels", lsb=2)
+
+
+def test_config3_full_size_gray(gpu, orc):
+    """config 3 at its real size: 3584 x 5376, B = G = R, QF = 90 (the reference's gray file
+    is absent, .MISSING_LARGE_BLOBS; imread would hand over three equal channels): chroma
+    planes are all zero, Y strips match the oracle, and the file round-trips."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    rows, cols = 3584, 5376
+    bgr = synth_image(rows, cols, 33, "gray", device=gpu)
+    assert bool((bgr[..., 0] == bgr[..., 1]).all()) and bool((bgr[..., 1] == bgr[..., 2]).all())
+    qy, qc = jpeg_amd.quality_tables(90)
+    coefs = jpeg_amd.encode_image(bgr, qy, qc)
+    assert not bool(coefs[1].any()) and not bool(coefs[2].any())  # Cb = Cr = 128 everywhere
+    rec = jpeg_amd.decode_image(*coefs, rows, cols, qy, qc)
+    assert bool((rec[..., 0] == rec[..., 1]).all()) and bool((rec[..., 1] == rec[..., 2]).all())
+    _strip_parity(orc, bgr, coefs, rec, qy, qc, (0, 100, rows // 16 - 1), "gray")
+    data = jpeg_amd.compress_image(bgr.cpu().numpy(), qy, qc)
+    back = jpeg_amd.decompress_image(data, qy, qc)
+    assert np.array_equal(back, rec.cpu().numpy())
+
+
+def test_config4_full_size_batch(gpu, orc):
+    """config 4 at its real image size (3840 x 2160: 7.5 wave tiles per row, so every MCU row
+    ends in a half-filled tile): images of a batch processed back to back on two streams equal
+    the same images processed alone, and sampled strips match the oracle."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    rows, cols = 2160, 3840
+    qy, qc = jpeg_amd.quality_tables(50)
+    imgs = [synth_image(rows, cols, seed, "photo", device=gpu) for seed in range(4)]
+    alone = [jpeg_amd.encode_image(im, qy, qc) for im in imgs]
+    recs = [jpeg_amd.decode_image(*c, rows, cols, qy, qc) for c in alone]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(2)]
+    outs, recs2 = [], []
+    for i, im in enumerate(imgs):
+        with torch.cuda.stream(streams[i & 1]):
+            c = jpeg_amd.encode_image(im, qy, qc)
+            outs.append(c)
+            recs2.append(jpeg_amd.decode_image(*c, rows, cols, qy, qc))
+    torch.cuda.synchronize()
+    for a, b, r, r2 in zip(alone, outs, recs, recs2):
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(r, r2)
+    _strip_parity(orc, imgs[3], alone[3], recs[3], qy, qc, (0, 67, rows // 16 - 1), "batch image 3")
+
+
+@pytest.mark.parametrize("qf", [1, 50, 100])
+def test_config5_full_size_quality(gpu, orc, qf):
+    """config 5 at its real size (4096^2) at both ends and the middle of the quality range"""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    rows = cols = 4096
+    bgr = synth_image(rows, cols, 4096 + qf, "photo", device=gpu)
+    qy, qc = jpeg_amd.quality_tables(qf)
+    coefs = jpeg_amd.encode_image(bgr, qy, qc)
+    rec = jpeg_amd.decode_image(*coefs, rows, cols, qy, qc)
+    _strip_parity(orc, bgr, coefs, rec, qy, qc, (0, 129, 255), f"QF={qf}")
+    again = jpeg_amd.encode_image(bgr, qy, qc)
+    assert all(torch.equal(x, y) for x, y in zip(coefs, again))  # deterministic
