@@ -372,61 +372,116 @@ int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
     int32_t *outs[3] = {sym_y, sym_cb, sym_cr};
     const size_t caps[3] = {cap_y, cap_cb, cap_cr};
     size_t *ns[3] = {n_y, n_cb, n_cr};
+    size_t dict_off[3];
     for (int c = 0; c < 3; ++c) {
         if (dsz[c] < 0 || (size_t)dsz[c] > (len - off) / 8)
             return fail("bin_decode: dictionary runs past the end of the file");
+        dict_off[c] = off;
+        off += (size_t)dsz[c] * 8;
+    }
+    // The three planes are independent streams: one thread each when the file is large.
+    // Workers only report a status; the message is set on the calling thread.
+    enum { kOk = 0, kNoCode = 1, kTooSmall = 2 };
+    int status[3] = {kOk, kOk, kOk};
+    auto decode_plane = [&](int c) {
         std::unordered_map<int, int> freq; // :1279: insertion in file order
-        for (int i = 0; i < dsz[c]; ++i, off += 8)
-            freq[get_i32(bin + off)] = get_i32(bin + off + 4);
+        for (int i = 0; i < dsz[c]; ++i)
+            freq[get_i32(bin + dict_off[c] + 8 * (size_t)i)] = get_i32(bin + dict_off[c] + 8 * (size_t)i + 4);
         Tree t;
         build_tree(std::vector<std::pair<int, int>>(freq.begin(), freq.end()), t); // decodeChannel, :664
         size_t n = 0;
         if (lens[c] > 0) {
-            if (t.root < 0 || t.leaf(t.root))
-                return fail("bin_decode: a plane with fewer than two distinct symbols has no decodable code "
-                            "(the reference dereferences a null child here, encode_decode.cpp:474)");
+            if (t.root < 0 || t.leaf(t.root)) {
+                status[c] = kNoCode;
+                return;
+            }
             // bitstreamToString(len * 8) + huffman_decode (:1261-1263, :468-482): every bit of
             // every byte, the zero padding included -- it may yield spurious trailing symbols.
-            // A 12-bit window resolves short codes in one step; longer ones continue bit by bit
-            // from the node the window reaches, so the symbol sequence is the bit-serial walk's.
-            constexpr int kWin = 12;
-            std::vector<int> win_node(1 << kWin), win_used(1 << kWin);
+            // A 12-bit window resolves up to four whole codes in one step (the average code is
+            // 2-3 bits); a code longer than the window continues bit by bit from the node the
+            // window reaches, so the symbol sequence is exactly the bit-serial walk's.
+            constexpr int kWin = 12, kMaxSym = 4;
+            struct Win {
+                int32_t sym[kMaxSym]; // values of the whole codes found, in order
+                int32_t node;         // count == 0: the inner node reached after kWin bits
+                uint8_t count, used;  // whole codes found / bits they take (kWin if count == 0)
+            };
+            std::vector<Win> win(1 << kWin);
             for (int v = 0; v < (1 << kWin); ++v) {
+                Win &w = win[v];
+                w = Win{};
                 int cur = t.root, used = 0;
-                while (used < kWin && !t.leaf(cur)) {
+                while (used < kWin) {
                     cur = ((v >> (kWin - 1 - used)) & 1) ? t.right[cur] : t.left[cur];
                     ++used;
+                    if (t.leaf(cur)) {
+                        w.sym[w.count++] = t.value[cur];
+                        w.used = (uint8_t)used;
+                        cur = t.root;
+                        if (w.count == kMaxSym)
+                            break;
+                    }
                 }
-                win_node[v] = cur, win_used[v] = used;
+                w.node = cur;
+                if (w.count == 0)
+                    w.used = kWin;
             }
             const unsigned long long nbits = (unsigned long long)lens[c] * 8;
             auto bit_at = [&](unsigned long long i) { return (payload[c][i >> 3] >> (7 - (i & 7))) & 1; };
+            int32_t *out = outs[c];
+            const size_t cap = out ? caps[c] : 0;
             unsigned long long pos = 0;
             while (pos < nbits) {
-                int cur;
+                int cur = t.root;
                 if (pos + 64 <= nbits) { // a whole window (and then some) is available
-                    uint64_t w;
-                    std::memcpy(&w, payload[c] + (pos >> 3), 8);
-                    w = __builtin_bswap64(w) << (pos & 7);
-                    const int v = (int)(w >> (64 - kWin));
-                    cur = win_node[v];
-                    pos += win_used[v];
-                } else {
-                    cur = t.root;
+                    uint64_t bits;
+                    std::memcpy(&bits, payload[c] + (pos >> 3), 8);
+                    bits = __builtin_bswap64(bits) << (pos & 7);
+                    const Win &w = win[(size_t)(bits >> (64 - kWin))];
+                    pos += w.used;
+                    if (w.count) {
+                        if (n + kMaxSym <= cap) { // room for all four slots: no per-symbol test
+                            for (int i = 0; i < kMaxSym; ++i)
+                                out[n + i] = w.sym[i];
+                        } else {
+                            for (int i = 0; i < w.count; ++i)
+                                if (n + i < cap)
+                                    out[n + i] = w.sym[i];
+                        }
+                        n += w.count;
+                        continue;
+                    }
+                    cur = w.node;
                 }
                 while (!t.leaf(cur) && pos < nbits)
                     cur = bit_at(pos++) ? t.right[cur] : t.left[cur];
                 if (!t.leaf(cur))
                     break; // ran out of bits inside a code: the reference emits nothing for it either
-                if (n < caps[c] && outs[c])
-                    outs[c][n] = t.value[cur];
+                if (n < cap)
+                    out[n] = t.value[cur];
                 ++n;
             }
         }
         *ns[c] = n; // the count found; more than cap means the caller's buffer was too small
         if (n > caps[c])
-            return fail("bin_decode: symbol buffer too small (the counts needed are in *n_y, *n_cb, *n_cr)");
+            status[c] = kTooSmall;
+    };
+    if ((size_t)lens[0] + (size_t)lens[1] + (size_t)lens[2] >= (1u << 18)) {
+        std::thread cb(decode_plane, 1), cr(decode_plane, 2);
+        decode_plane(0);
+        cb.join();
+        cr.join();
+    } else {
+        for (int c = 0; c < 3; ++c)
+            decode_plane(c);
     }
+    for (int c = 0; c < 3; ++c)
+        if (status[c] == kNoCode)
+            return fail("bin_decode: a plane with fewer than two distinct symbols has no decodable code "
+                        "(the reference dereferences a null child here, encode_decode.cpp:474)");
+    for (int c = 0; c < 3; ++c)
+        if (status[c] == kTooSmall)
+            return fail("bin_decode: symbol buffer too small (the counts needed are in *n_y, *n_cb, *n_cr)");
     return 0;
 }
 

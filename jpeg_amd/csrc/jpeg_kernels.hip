@@ -229,22 +229,27 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     // time the loads issued four tasks earlier have landed.  Task T = 8*it + t covers
     // 2 rows x 4 pixels per lane: row pair rp = t>>1, pixel group g = lane + 64*(t&1).
     // Loads are unconditional: lanes beyond the image edge re-read its last pixel group,
-    // tasks beyond 15 re-read task 15.
+    // tasks beyond 15 re-read tasks 14 and 15.
     constexpr int kRing = 4;
-    auto task_load = [&](int T, U3 &a, U3 &b) {
-        T = T < 15 ? T : 15;
-        const int t = T & 7;
-        const int row = ty * 16 + (T >> 3) * 8 + 2 * (t >> 1);
-        int x = x0 + 4 * (lane + 64 * (t & 1));
+    // The row base is uniform (scalar registers) and the lane's byte offset within a row
+    // takes only two values, so a load costs no vector arithmetic: saddr + 32-bit voffset.
+    uint32_t lane_off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int x = x0 + 4 * (lane + 64 * h);
         x = x < cols - 4 ? x : cols - 4;
-        const uint8_t *p = bgr + (size_t)row * stride + (size_t)x * 3;
-        a = *reinterpret_cast<const U3 *>(p);
-        b = *reinterpret_cast<const U3 *>(p + stride);
+        lane_off[h] = 3u * (uint32_t)x;
+    }
+    auto task_load = [&](int T, int odd, U3 &a, U3 &b) { // odd == T & 1, a compile-time constant at every call
+        T = T < 16 ? T : 14 + odd;
+        const uint8_t *rowp = bgr + (size_t)(ty * 16 + 2 * (T >> 1)) * stride;
+        a = *reinterpret_cast<const U3 *>(rowp + lane_off[odd]);
+        b = *reinterpret_cast<const U3 *>(rowp + stride + lane_off[odd]);
     };
     U3 ring_a[kRing], ring_b[kRing];
 #pragma unroll
     for (int i = 0; i < kRing; ++i)
-        task_load(i, ring_a[i], ring_b[i]);
+        task_load(i, i & 1, ring_a[i], ring_b[i]);
 
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
             U3 next_a[kRing], next_b[kRing];
 #pragma unroll
             for (int i = 0; i < kRing; ++i)
-                task_load(it * 8 + t0 + kRing + i, next_a[i], next_b[i]);
+                task_load(it * 8 + t0 + kRing + i, i & 1, next_a[i], next_b[i]);
 #pragma unroll
             for (int slot = 0; slot < kRing; ++slot) {
                 const int t = t0 + slot;
