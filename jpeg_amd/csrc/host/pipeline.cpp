@@ -7,8 +7,6 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 #include "../../../include/jpeg_amd.h"
@@ -16,126 +14,6 @@
 
 namespace {
 
-// ---- host <-> device copies of pageable memory ------------------------------------------
-// hipMemcpy on pageable memory moves about 5 GB/s on the box (8192^2: 40 ms each way, far
-// more than every kernel together).  Four worker threads, each with two pinned 4 MiB staging
-// buffers and its own stream, copy row ranges instead: the CPU fills (or drains) one buffer
-// while the DMA engine moves the other.  The pool is created once per process and device
-// and serialises concurrent callers.
-class StagedCopier {
-public:
-    // `rows` rows of `width` bytes between a dense device buffer and host rows `hpitch` apart
-    int copy(void *dev, uint8_t *host, size_t hpitch, size_t width, size_t rows, bool to_device)
-    {
-        const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
-        if (rows == 0 || width == 0)
-            return 0;
-        if (width * rows < (1u << 20) || width > kChunk) { // small, or rows wider than a staging buffer
-            if (to_device)
-                JPEGAMD_HIPCHK(hipMemcpy2D(dev, width, host, hpitch, width, rows, kind));
-            else
-                JPEGAMD_HIPCHK(hipMemcpy2D(host, hpitch, dev, width, width, rows, kind));
-            return 0;
-        }
-        std::lock_guard<std::mutex> lock(mu_);
-        int device = 0;
-        JPEGAMD_HIPCHK(hipGetDevice(&device));
-        if (prepare(device))
-            return 1;
-        hipError_t err[kThreads];
-        std::thread th[kThreads];
-        for (int t = 0; t < kThreads; ++t) {
-            const size_t r0 = rows * t / kThreads, r1 = rows * (t + 1) / kThreads;
-            th[t] = std::thread([=, &err] {
-                err[t] = worker(t, device, static_cast<uint8_t *>(dev) + r0 * width, host + r0 * hpitch, hpitch, width,
-                                r1 - r0, to_device);
-            });
-        }
-        for (auto &x : th)
-            x.join();
-        for (int t = 0; t < kThreads; ++t)
-            if (err[t] != hipSuccess)
-                return jpegamd_fail("staged copy: %s", hipGetErrorString(err[t]));
-        return 0;
-    }
-
-private:
-    static constexpr int kThreads = 4;
-    static constexpr size_t kChunk = 4u << 20;
-    std::mutex mu_;
-    int device_ = -1;
-    void *pin_[kThreads][2] = {};
-    hipStream_t stream_[kThreads] = {};
-    hipEvent_t done_[kThreads][2] = {};
-
-    int prepare(int device)
-    {
-        if (device_ == device)
-            return 0;
-        for (int t = 0; t < kThreads; ++t) { // first use, or another device: (re)create streams and events
-            if (stream_[t]) {
-                (void)hipStreamDestroy(stream_[t]);
-                (void)hipEventDestroy(done_[t][0]);
-                (void)hipEventDestroy(done_[t][1]);
-                stream_[t] = nullptr;
-            }
-            for (int b = 0; b < 2; ++b)
-                if (!pin_[t][b])
-                    JPEGAMD_HIPCHK(hipHostMalloc(&pin_[t][b], kChunk, hipHostMallocPortable));
-            JPEGAMD_HIPCHK(hipStreamCreateWithFlags(&stream_[t], hipStreamNonBlocking));
-            JPEGAMD_HIPCHK(hipEventCreateWithFlags(&done_[t][0], hipEventDisableTiming));
-            JPEGAMD_HIPCHK(hipEventCreateWithFlags(&done_[t][1], hipEventDisableTiming));
-        }
-        device_ = device;
-        return 0;
-    }
-
-    hipError_t worker(int t, int device, uint8_t *dev, uint8_t *host, size_t hpitch, size_t width, size_t rows,
-                      bool to_device)
-    {
-        hipError_t e = hipSetDevice(device); // the current device is per thread
-        const size_t per = std::max<size_t>(1, kChunk / width); // rows per chunk
-        const size_t chunks = (rows + per - 1) / per;
-        auto span = [&](size_t i) { return std::min(per, rows - i * per); };
-        auto host_rows = [&](size_t i, int slot, bool fill) { // pageable rows <-> packed pinned rows
-            uint8_t *pin = static_cast<uint8_t *>(pin_[t][slot]);
-            for (size_t r = 0; r < span(i); ++r) {
-                uint8_t *h = host + (i * per + r) * hpitch;
-                if (fill)
-                    std::memcpy(pin + r * width, h, width);
-                else
-                    std::memcpy(h, pin + r * width, width);
-            }
-        };
-        for (size_t i = 0; i < chunks && e == hipSuccess; ++i) {
-            const int slot = (int)(i & 1);
-            if (to_device) {
-                if (i >= 2)
-                    e = hipEventSynchronize(done_[t][slot]); // the DMA that last read this buffer
-                host_rows(i, slot, true);
-                if (e == hipSuccess)
-                    e = hipMemcpyAsync(dev + i * per * width, pin_[t][slot], span(i) * width, hipMemcpyHostToDevice,
-                                       stream_[t]);
-            } else {
-                e = hipMemcpyAsync(pin_[t][slot], dev + i * per * width, span(i) * width, hipMemcpyDeviceToHost,
-                                   stream_[t]);
-            }
-            if (e == hipSuccess)
-                e = hipEventRecord(done_[t][slot], stream_[t]);
-            if (!to_device && i >= 1 && e == hipSuccess) { // drain the previous chunk while this one moves
-                e = hipEventSynchronize(done_[t][slot ^ 1]);
-                host_rows(i - 1, slot ^ 1, false);
-            }
-        }
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(stream_[t]);
-        if (!to_device && e == hipSuccess && chunks)
-            host_rows(chunks - 1, (int)((chunks - 1) & 1), false);
-        return e;
-    }
-};
-
-StagedCopier g_copier;
 
 struct DevMem {
     void *p = nullptr;
@@ -187,13 +65,8 @@ int plane_symbols(const int16_t *d_coef, size_t nb, HostSymbols &sym)
         if (total <= cap) {
             if (!sym.resize((size_t)total * 2))
                 return jpegamd_fail("compress_image: out of host memory");
-            if (total && g_copier.copy(pairs.p, reinterpret_cast<uint8_t *>(sym.data()), 4096, 4096,
-                                       ((size_t)total * 8) / 4096, false))
+            if (total && jpegamd_staged_copy_linear(pairs.p, sym.data(), (size_t)total * 8, false))
                 return 1;
-            const size_t tail = ((size_t)total * 8) % 4096, head = (size_t)total * 8 - tail;
-            if (tail)
-                JPEGAMD_HIPCHK(hipMemcpy(reinterpret_cast<uint8_t *>(sym.data()) + head,
-                                         static_cast<uint8_t *>(pairs.p) + head, tail, hipMemcpyDeviceToHost));
             return 0;
         }
         cap = total;
@@ -242,7 +115,7 @@ int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride
     DevMem d_bgr, d_y, d_cb, d_cr;
     if (d_bgr.alloc((size_t)rows * cols * 3) || d_y.alloc(nby * 128) || d_cb.alloc(nbc * 128) || d_cr.alloc(nbc * 128))
         return jpegamd_fail("compress_image: out of device memory");
-    if (g_copier.copy(d_bgr.p, const_cast<uint8_t *>(bgr), stride, (size_t)cols * 3, rows, true))
+    if (jpegamd_staged_copy(d_bgr.p, const_cast<uint8_t *>(bgr), stride, (size_t)cols * 3, rows, true))
         return 1;
     if (jpegamd_encode_image_dev(d_bgr.as<uint8_t>(), rows, cols, (size_t)cols * 3, q_luma, q_chroma,
                                  d_y.as<int16_t>(), d_cb.as<int16_t>(), d_cr.as<int16_t>(), nullptr))
@@ -320,14 +193,8 @@ int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_lum
         const size_t wbytes = jpegamd_rle_workspace_bytes(nb[k]);
         if (d_coef[k].alloc(nb[k] * 128) || d_pairs.alloc(use * 8) || work.alloc(wbytes))
             return jpegamd_fail("decompress_image: out of device memory");
-        if (use) { // whole 4 KiB rows through the staged copier, the tail directly
-            const size_t bytes = use * 8, tail = bytes % 4096, head = bytes - tail;
-            if (head && g_copier.copy(d_pairs.p, reinterpret_cast<uint8_t *>(sym[k].p), 4096, 4096, head / 4096, true))
-                return 1;
-            if (tail)
-                JPEGAMD_HIPCHK(hipMemcpy(static_cast<uint8_t *>(d_pairs.p) + head,
-                                         reinterpret_cast<uint8_t *>(sym[k].p) + head, tail, hipMemcpyHostToDevice));
-        }
+        if (use && jpegamd_staged_copy_linear(d_pairs.p, sym[k].p, use * 8, true))
+            return 1;
         if (jpegamd_rle_decode_plane_dev(d_pairs.as<int32_t>(), use, nb[k], d_coef[k].as<int16_t>(), work.p, wbytes,
                                          nullptr))
             return 1;
@@ -339,7 +206,7 @@ int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_lum
                                  q_luma, q_chroma, d_out.as<uint8_t>(), (size_t)c * 3, nullptr))
         return 1;
     JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the decode kernel ran on the null stream, the copier uses its own
-    return g_copier.copy(d_out.p, bgr, stride, (size_t)c * 3, r, false);
+    return jpegamd_staged_copy(d_out.p, bgr, stride, (size_t)c * 3, r, false);
 }
 
 } // extern "C"

@@ -1,0 +1,154 @@
+// staged_copy.cpp -- copies between pageable host memory and the device at bus speed.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "../host_common.h"
+
+namespace {
+
+// ---- host <-> device copies of pageable memory ------------------------------------------
+// hipMemcpy on pageable memory moves about 5 GB/s on the box (8192^2: 40 ms each way, far
+// more than every kernel together).  Four worker threads, each with two pinned 4 MiB staging
+// buffers and its own stream, copy row ranges instead: the CPU fills (or drains) one buffer
+// while the DMA engine moves the other.  The pool is created once per process and device
+// and serialises concurrent callers.
+class StagedCopier {
+public:
+    // `rows` rows of `width` bytes between a dense device buffer and host rows `hpitch` apart
+    int copy(void *dev, uint8_t *host, size_t hpitch, size_t width, size_t rows, bool to_device)
+    {
+        const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+        if (rows == 0 || width == 0)
+            return 0;
+        if (width * rows < (1u << 20) || width > kChunk) { // small, or rows wider than a staging buffer
+            if (to_device)
+                JPEGAMD_HIPCHK(hipMemcpy2D(dev, width, host, hpitch, width, rows, kind));
+            else
+                JPEGAMD_HIPCHK(hipMemcpy2D(host, hpitch, dev, width, width, rows, kind));
+            return 0;
+        }
+        std::lock_guard<std::mutex> lock(mu_);
+        int device = 0;
+        JPEGAMD_HIPCHK(hipGetDevice(&device));
+        if (prepare(device))
+            return 1;
+        hipError_t err[kThreads];
+        std::thread th[kThreads];
+        for (int t = 0; t < kThreads; ++t) {
+            const size_t r0 = rows * t / kThreads, r1 = rows * (t + 1) / kThreads;
+            th[t] = std::thread([=, &err] {
+                err[t] = worker(t, device, static_cast<uint8_t *>(dev) + r0 * width, host + r0 * hpitch, hpitch, width,
+                                r1 - r0, to_device);
+            });
+        }
+        for (auto &x : th)
+            x.join();
+        for (int t = 0; t < kThreads; ++t)
+            if (err[t] != hipSuccess)
+                return jpegamd_fail("staged copy: %s", hipGetErrorString(err[t]));
+        return 0;
+    }
+
+private:
+    static constexpr int kThreads = 4;
+    static constexpr size_t kChunk = 4u << 20;
+    std::mutex mu_;
+    int device_ = -1;
+    void *pin_[kThreads][2] = {};
+    hipStream_t stream_[kThreads] = {};
+    hipEvent_t done_[kThreads][2] = {};
+
+    int prepare(int device)
+    {
+        if (device_ == device)
+            return 0;
+        for (int t = 0; t < kThreads; ++t) { // first use, or another device: (re)create streams and events
+            if (stream_[t]) {
+                (void)hipStreamDestroy(stream_[t]);
+                (void)hipEventDestroy(done_[t][0]);
+                (void)hipEventDestroy(done_[t][1]);
+                stream_[t] = nullptr;
+            }
+            for (int b = 0; b < 2; ++b)
+                if (!pin_[t][b])
+                    JPEGAMD_HIPCHK(hipHostMalloc(&pin_[t][b], kChunk, hipHostMallocPortable));
+            JPEGAMD_HIPCHK(hipStreamCreateWithFlags(&stream_[t], hipStreamNonBlocking));
+            JPEGAMD_HIPCHK(hipEventCreateWithFlags(&done_[t][0], hipEventDisableTiming));
+            JPEGAMD_HIPCHK(hipEventCreateWithFlags(&done_[t][1], hipEventDisableTiming));
+        }
+        device_ = device;
+        return 0;
+    }
+
+    hipError_t worker(int t, int device, uint8_t *dev, uint8_t *host, size_t hpitch, size_t width, size_t rows,
+                      bool to_device)
+    {
+        hipError_t e = hipSetDevice(device); // the current device is per thread
+        const size_t per = std::max<size_t>(1, kChunk / width); // rows per chunk
+        const size_t chunks = (rows + per - 1) / per;
+        auto span = [&](size_t i) { return std::min(per, rows - i * per); };
+        auto host_rows = [&](size_t i, int slot, bool fill) { // pageable rows <-> packed pinned rows
+            uint8_t *pin = static_cast<uint8_t *>(pin_[t][slot]);
+            for (size_t r = 0; r < span(i); ++r) {
+                uint8_t *h = host + (i * per + r) * hpitch;
+                if (fill)
+                    std::memcpy(pin + r * width, h, width);
+                else
+                    std::memcpy(h, pin + r * width, width);
+            }
+        };
+        for (size_t i = 0; i < chunks && e == hipSuccess; ++i) {
+            const int slot = (int)(i & 1);
+            if (to_device) {
+                if (i >= 2)
+                    e = hipEventSynchronize(done_[t][slot]); // the DMA that last read this buffer
+                host_rows(i, slot, true);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(dev + i * per * width, pin_[t][slot], span(i) * width, hipMemcpyHostToDevice,
+                                       stream_[t]);
+            } else {
+                e = hipMemcpyAsync(pin_[t][slot], dev + i * per * width, span(i) * width, hipMemcpyDeviceToHost,
+                                   stream_[t]);
+            }
+            if (e == hipSuccess)
+                e = hipEventRecord(done_[t][slot], stream_[t]);
+            if (!to_device && i >= 1 && e == hipSuccess) { // drain the previous chunk while this one moves
+                e = hipEventSynchronize(done_[t][slot ^ 1]);
+                host_rows(i - 1, slot ^ 1, false);
+            }
+        }
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(stream_[t]);
+        if (!to_device && e == hipSuccess && chunks)
+            host_rows(chunks - 1, (int)((chunks - 1) & 1), false);
+        return e;
+    }
+};
+
+StagedCopier g_copier;
+
+} // namespace
+
+int jpegamd_staged_copy(void *dev, uint8_t *host, size_t hpitch, size_t width, size_t rows, bool to_device)
+{
+    return g_copier.copy(dev, host, hpitch, width, rows, to_device);
+}
+
+// one contiguous range: whole 4 KiB rows through the staged copier, the tail directly
+int jpegamd_staged_copy_linear(void *dev, void *host, size_t bytes, bool to_device)
+{
+    const size_t tail = bytes % 4096, head = bytes - tail;
+    if (head && g_copier.copy(dev, static_cast<uint8_t *>(host), 4096, 4096, head / 4096, to_device))
+        return 1;
+    if (tail) {
+        uint8_t *d = static_cast<uint8_t *>(dev) + head, *h = static_cast<uint8_t *>(host) + head;
+        if (to_device)
+            JPEGAMD_HIPCHK(hipMemcpy(d, h, tail, hipMemcpyHostToDevice));
+        else
+            JPEGAMD_HIPCHK(hipMemcpy(h, d, tail, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}

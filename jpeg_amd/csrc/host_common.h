@@ -1,10 +1,21 @@
-// host_common.h -- error reporting shared by the translation units of libjpeg_amd.so
+// host_common.h -- error reporting and host<->device copies shared by the translation units of libjpeg_amd.so
 #ifndef JPEGAMD_HOST_COMMON_H
 #define JPEGAMD_HOST_COMMON_H
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+#include <cstdint>
+
 // stores the message for jpegamd_last_error() (thread-local) and returns 1
 __attribute__((visibility("hidden"), format(printf, 1, 2))) int jpegamd_fail(const char *fmt, ...);
+
+// `rows` rows of `width` bytes between a dense device buffer and (pageable) host rows `hpitch`
+// apart, through pinned staging buffers on worker threads (host/staged_copy.cpp); returns
+// when the data has arrived.  The _linear form takes one contiguous range.
+__attribute__((visibility("hidden"))) int jpegamd_staged_copy(void *dev, uint8_t *host, size_t hpitch, size_t width,
+                                                              size_t rows, bool to_device);
+__attribute__((visibility("hidden"))) int jpegamd_staged_copy_linear(void *dev, void *host, size_t bytes,
+                                                                     bool to_device);
 
 #define JPEGAMD_HIPCHK(expr)                                                                          \
     do {                                                                                              \

@@ -1413,13 +1413,15 @@ int jpegamd_encode_image(const uint8_t *bgr, int rows, int cols, size_t stride,
     HIPCHK(hipMalloc(&cy.p, ny * 2));
     HIPCHK(hipMalloc(&cb.p, nc * 2));
     HIPCHK(hipMalloc(&cr.p, nc * 2));
-    HIPCHK(hipMemcpy2D(img.p, dstride, bgr, stride, dstride, rows, hipMemcpyHostToDevice));
+    if (jpegamd_staged_copy(img.p, const_cast<uint8_t *>(bgr), stride, dstride, rows, true))
+        return 1;
     if (jpegamd_encode_image_dev((const uint8_t *)img.p, rows, cols, dstride, q_luma, q_chroma,
                                  (int16_t *)cy.p, (int16_t *)cb.p, (int16_t *)cr.p, nullptr))
         return 1;
-    HIPCHK(hipMemcpy(coef_y, cy.p, ny * 2, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(coef_cb, cb.p, nc * 2, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(coef_cr, cr.p, nc * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipDeviceSynchronize()); // the kernel ran on the null stream, the copier uses its own
+    if (jpegamd_staged_copy_linear(cy.p, coef_y, ny * 2, false) || jpegamd_staged_copy_linear(cb.p, coef_cb, nc * 2, false) ||
+        jpegamd_staged_copy_linear(cr.p, coef_cr, nc * 2, false))
+        return 1;
     return 0;
 }
 
@@ -1438,13 +1440,16 @@ int jpegamd_decode_image(const int16_t *coef_y, const int16_t *coef_cb, const in
     HIPCHK(hipMalloc(&cy.p, ny * 2));
     HIPCHK(hipMalloc(&cb.p, nc * 2));
     HIPCHK(hipMalloc(&cr.p, nc * 2));
-    HIPCHK(hipMemcpy(cy.p, coef_y, ny * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(cb.p, coef_cb, nc * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(cr.p, coef_cr, nc * 2, hipMemcpyHostToDevice));
+    if (jpegamd_staged_copy_linear(cy.p, const_cast<int16_t *>(coef_y), ny * 2, true) ||
+        jpegamd_staged_copy_linear(cb.p, const_cast<int16_t *>(coef_cb), nc * 2, true) ||
+        jpegamd_staged_copy_linear(cr.p, const_cast<int16_t *>(coef_cr), nc * 2, true))
+        return 1;
     if (jpegamd_decode_image_dev((const int16_t *)cy.p, (const int16_t *)cb.p, (const int16_t *)cr.p, rows, cols,
                                  q_luma, q_chroma, (uint8_t *)img.p, dstride, nullptr))
         return 1;
-    HIPCHK(hipMemcpy2D(bgr, stride, img.p, dstride, dstride, rows, hipMemcpyDeviceToHost));
+    HIPCHK(hipDeviceSynchronize()); // the kernel ran on the null stream, the copier uses its own
+    if (jpegamd_staged_copy(img.p, bgr, stride, dstride, rows, false))
+        return 1;
     return 0;
 }
 

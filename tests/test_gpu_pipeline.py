@@ -52,3 +52,33 @@ def test_pipeline_errors(gpu):
         jpeg_amd.compress_image(np.zeros((20, 16, 3), np.uint8), qy, qc)
     with pytest.raises(jpeg_amd.JpegAmdError):
         jpeg_amd.decompress_image(b"\x00" * 20, qy, qc)
+
+
+def test_host_pointer_entry_points_with_row_pitch(gpu):
+    """jpegamd_encode_image / jpegamd_decode_image on pageable host memory (the level-1 boundary
+    of INTEGRATION.md): large enough for the staged copier, and with a row pitch wider than the
+    image, like a cv::Mat ROI.  Must equal the device-pointer path bit for bit."""
+    import torch
+    import jpeg_amd
+    from jpeg_amd import _lib
+    from jpeg_amd.synth import synth_image
+    lib = _lib.load()
+    rows, cols, pitch = 1040, 2064, 2064 * 3 + 52
+    img = synth_image(rows, cols, 77, "photo").numpy()
+    padded = np.full((rows, pitch), 0xAB, np.uint8)
+    padded[:, :cols * 3] = img.reshape(rows, cols * 3)
+    qy, qc = jpeg_amd.quality_tables(75)
+    qy32, qc32 = np.ascontiguousarray(qy, np.int32), np.ascontiguousarray(qc, np.int32)
+    ny, nc = rows * cols, rows * cols // 4
+    cy, cb, cr = np.empty(ny, np.int16), np.empty(nc, np.int16), np.empty(nc, np.int16)
+    _lib.check(lib.jpegamd_encode_image(padded.ctypes.data, rows, cols, pitch, qy32.ctypes.data, qc32.ctypes.data,
+                                        cy.ctypes.data, cb.ctypes.data, cr.ctypes.data))
+    want = jpeg_amd.encode_image(torch.from_numpy(img).to(gpu), qy, qc)
+    for g, w in zip((cy, cb, cr), want):
+        assert np.array_equal(g.reshape(-1, 64), w.cpu().numpy())
+    out = np.full((rows, pitch), 0xCD, np.uint8)
+    _lib.check(lib.jpegamd_decode_image(cy.ctypes.data, cb.ctypes.data, cr.ctypes.data, rows, cols,
+                                        qy32.ctypes.data, qc32.ctypes.data, out.ctypes.data, pitch))
+    rec = jpeg_amd.decode_image(*want, rows, cols, qy, qc).cpu().numpy()
+    assert np.array_equal(out[:, :cols * 3].reshape(rows, cols, 3), rec)
+    assert (out[:, cols * 3:] == 0xCD).all()  # the padding of every row is left alone
