@@ -26,11 +26,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 BYTES_PER_PIXEL_ENC = 6.0  # 3 B BGR read + 1.5 coefficients x 2 B written
 BYTES_PER_PIXEL_DEC = 6.0  # 3 B coefficients read + 3 B BGR written
 # HBM bytes per launch at 8192^2 QF=50 from rocprofv3 PMC passes (separate --pmc runs of
-# tools/prof_run.py, profiles/r01_e_pmc_hbm_traffic.txt): FETCH_SIZE x 2 (the gfx950
+# tools/prof_run.py, profiles/r01_f_pmc_hbm_traffic.txt): FETCH_SIZE x 2 (the gfx950
 # correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both reported in KiB.
 MEASURED_TRAFFIC = {
-    (8192, 8192, 50): {"encode_image_kernel": (99178 * 2 + 196608) * 1024,
-                       "decode_image_kernel": (98576 * 2 + 196608) * 1024},
+    (8192, 8192, 50): {"encode_image_kernel": (98562 * 2 + 196608) * 1024,
+                       "decode_image_kernel": (98538 * 2 + 196619) * 1024},
 }
 
 

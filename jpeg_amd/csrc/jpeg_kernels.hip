@@ -53,6 +53,21 @@ struct __attribute__((aligned(4))) U3 {
     uint32_t a, b, c;
 };
 
+// Streaming accesses.  Every byte of the image and of the coefficient planes is touched
+// exactly once, so the stores carry the nontemporal hint: the lines are not kept in L2 and
+// do not compete with the loads for it.  Measured at 8192^2: decoder 84.2 -> 66 us, encoder
+// 104 -> 99 us.  The same hint on the LOADS costs 10 us in the decoder (76.6 us) and 1.5 us
+// in the encoder, so they stay plain.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ void store16_stream(void *p, uint4 v)
+{
+    __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, static_cast<u32x4_t *>(p));
+}
+__device__ __forceinline__ void store12_stream(void *p, const U3 &v)
+{
+    __builtin_nontemporal_store(u32x3_t{v.a, v.b, v.c}, static_cast<u32x3_t *>(p));
+}
 __device__ __forceinline__ void wave_lds_fence()
 {
     // LDS operations of one wave are issued and retired in order; this only
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                 const int b = (luma ? k * 8 : (k & 3) * 8) + blk; // block index within its plane's run
                 if (b < n_ok) {
                     uint4 d = *reinterpret_cast<const uint4 *>(sp + k * 8 * kStagePitch);
-                    *reinterpret_cast<uint4 *>((k < 4 ? base_a : base_b) + (k & 3) * 1024 + lane * 16) = d;
+                    store16_stream((k < 4 ? base_a : base_b) + (k & 3) * 1024 + lane * 16, d);
                 }
             }
         }
@@ -498,8 +513,8 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
                         jm_inv_row4_exact(yb, cb0, cr0, cb1, cr1, wb.a, wb.b, wb.c);
                     }
                     uint8_t *p0 = bgr + (size_t)(row_base + 2 * rp) * stride + (size_t)x * 3;
-                    *reinterpret_cast<U3 *>(p0) = wa;
-                    *reinterpret_cast<U3 *>(p0 + stride) = wb;
+                    store12_stream(p0, wa);
+                    store12_stream(p0 + stride, wb);
                 }
             }
             wave_lds_fence(); // Y rows consumed before the next round stages over them
@@ -619,7 +634,7 @@ __device__ __forceinline__ void mfma_round(const uint32_t (&a4)[8], const float 
     for (int i = 0; i < 4; ++i) {
         if ((i & 1) * 8 + blk < n_ok) {
             uint4 d = *reinterpret_cast<const uint4 *>(stage + (i >> 1) * kStageHalf + (i & 1) * 1024 + lane * 16);
-            *reinterpret_cast<uint4 *>(((i >> 1) ? dst1 : dst0) + (i & 1) * 1024 + lane * 16) = d;
+            store16_stream(((i >> 1) ? dst1 : dst0) + (i & 1) * 1024 + lane * 16, d);
         }
     }
     wave_lds_fence(); // staged blocks are read (in-order LDS) before the next round overwrites them
@@ -884,7 +899,7 @@ __device__ __forceinline__ void xdl_transform_strip(const uint8_t *src, int pitc
         for (int i = 0; i < 4; ++i) {
             if (32 * round + i * 8 + blk < n_ok) {
                 uint4 d = *reinterpret_cast<const uint4 *>(stage + (i * 8 + blk) * kStagePitch + (lane & 7) * 16);
-                *reinterpret_cast<uint4 *>(dst + round * 4096 + i * 1024 + lane * 16) = d;
+                store16_stream(dst + round * 4096 + i * 1024 + lane * 16, d);
             }
         }
         wave_lds_fence(); // staged blocks are read (in-order LDS) before the next round overwrites them
