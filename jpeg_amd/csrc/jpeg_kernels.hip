@@ -381,12 +381,24 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
             }
             const int blk = lane >> 3;
             const uint8_t *sp = stage + blk * kStagePitch + (lane & 7) * 16;
+            if (n_ok >= (luma ? 64 : 32)) {
+                // the whole round lies inside the plane (every tile but the last of a row): all
+                // eight LDS reads in flight at once, then the eight stores
+                uint4 d[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int b = (luma ? k * 8 : (k & 3) * 8) + blk; // block index within its plane's run
-                if (b < n_ok) {
-                    uint4 d = *reinterpret_cast<const uint4 *>(sp + k * 8 * kStagePitch);
-                    store16_stream((k < 4 ? base_a : base_b) + (k & 3) * 1024 + lane * 16, d);
+                for (int k = 0; k < 8; ++k)
+                    d[k] = *reinterpret_cast<const uint4 *>(sp + k * 8 * kStagePitch);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    store16_stream((k < 4 ? base_a : base_b) + (k & 3) * 1024 + lane * 16, d[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int b = (luma ? k * 8 : (k & 3) * 8) + blk; // block index within its plane's run
+                    if (b < n_ok) {
+                        uint4 d = *reinterpret_cast<const uint4 *>(sp + k * 8 * kStagePitch);
+                        store16_stream((k < 4 ? base_a : base_b) + (k & 3) * 1024 + lane * 16, d);
+                    }
                 }
             }
         }
@@ -895,11 +907,21 @@ __device__ __forceinline__ void xdl_transform_strip(const uint8_t *src, int pitc
             }
         }
         wave_lds_fence();
+        if (32 * round + 32 <= n_ok) { // the whole round lies inside the plane: reads first, then stores
+            uint4 d[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (32 * round + i * 8 + blk < n_ok) {
-                uint4 d = *reinterpret_cast<const uint4 *>(stage + (i * 8 + blk) * kStagePitch + (lane & 7) * 16);
-                store16_stream(dst + round * 4096 + i * 1024 + lane * 16, d);
+            for (int i = 0; i < 4; ++i)
+                d[i] = *reinterpret_cast<const uint4 *>(stage + (i * 8 + blk) * kStagePitch + (lane & 7) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                store16_stream(dst + round * 4096 + i * 1024 + lane * 16, d[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (32 * round + i * 8 + blk < n_ok) {
+                    uint4 d = *reinterpret_cast<const uint4 *>(stage + (i * 8 + blk) * kStagePitch + (lane & 7) * 16);
+                    store16_stream(dst + round * 4096 + i * 1024 + lane * 16, d);
+                }
             }
         }
         wave_lds_fence(); // staged blocks are read (in-order LDS) before the next round overwrites them
