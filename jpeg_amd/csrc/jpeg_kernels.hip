@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256) void encode_plane_kernel(
         if (gx * 64 + b < bw) {
             uint4 d = *reinterpret_cast<const uint4 *>(stage + b * kStagePitch + part * 16);
             uint8_t *dst = reinterpret_cast<uint8_t *>(coef + ((size_t)by * bw + gx * 64 + b) * 64);
-            *reinterpret_cast<uint4 *>(dst + part * 16) = d;
+            store16_stream(dst + part * 16, d);
         }
     }
 }
