@@ -64,6 +64,11 @@ __device__ __forceinline__ void store16_stream(void *p, uint4 v)
 {
     __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, static_cast<u32x4_t *>(p));
 }
+__device__ __forceinline__ void store8_stream(void *p, uint2 v)
+{
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(u32x2_t{v.x, v.y}, static_cast<u32x2_t *>(p));
+}
 __device__ __forceinline__ void store12_stream(void *p, const U3 &v)
 {
     __builtin_nontemporal_store(u32x3_t{v.a, v.b, v.c}, static_cast<u32x3_t *>(p));
@@ -1137,7 +1142,7 @@ __global__ __launch_bounds__(256) void decode_plane_kernel(
             for (int r = 0; r < 8; ++r) {
                 uint32_t lo = jm_pack4_u8(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]);
                 uint32_t hi = jm_pack4_u8(v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
-                *reinterpret_cast<uint2 *>(plane + (size_t)(r0 + r) * stride + c0) = make_uint2(lo, hi);
+                store8_stream(plane + (size_t)(r0 + r) * stride + c0, make_uint2(lo, hi));
             }
         } else {
 #pragma unroll
