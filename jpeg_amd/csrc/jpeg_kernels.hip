@@ -49,6 +49,8 @@ constexpr int kChromaBytes = 2 * 8 * 256;     // Cb + Cr, 8 rows x 256 samples
 constexpr int kWaveLds = kStageBytes + kChromaBytes; // 13312
 constexpr int kWavesPerWg = 4;
 
+typedef __attribute__((address_space(3))) uint8_t lds_u8; // a byte in LDS, for stores that must stay byte stores
+
 struct __attribute__((aligned(4))) U3 {
     uint32_t a, b, c;
 };
@@ -322,8 +324,9 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                         }
                     }
                     // bytes go to LDS one by one (the low byte of each magic float): byte stores
-                    // ride the LDS queue, packing them first would cost ten VALU permutes
-                    uint8_t *y0 = stage + (2 * rp) * 512 + 4 * g;
+                    // ride the LDS queue, packing them first costs 16 VALU instructions per task
+                    // (volatile: left alone, the compiler merges the stores and packs)
+                    volatile lds_u8 *y0 = (volatile lds_u8 *)(stage + (2 * rp) * 512 + 4 * g);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         y0[j] = (uint8_t)jm_bits(ya[j]);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                     }
                     // chromaSubsampling: truncating mean of the quad (:139-149)
                     const int crow = it * 4 + rp;
-                    uint8_t *c0 = cbuf + crow * 256 + 2 * g;
+                    volatile lds_u8 *c0 = (volatile lds_u8 *)(cbuf + crow * 256 + 2 * g);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         c0[q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[q]));
