@@ -134,6 +134,16 @@ int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
                        int32_t *sym_cr, size_t cap_cr, size_t *n_cr);
 
 /* ---- whole image, HOST buffers ------------------------------------------------ */
+/* The same container from symbol streams that are already on the device (e.g. the pair
+ * streams of jpegamd_rle_encode_plane_dev): histogram, first-occurrence order, code lookup
+ * and bit packing run on the GPU (entropy_kernels.hip), the order-defining containers
+ * (std::unordered_map, std::priority_queue; encode_decode.cpp:375-456) on the host; `out`
+ * is host memory.  Inputs outside the device tables (a symbol beyond int16, a code longer
+ * than 32 bits) take the host coder.  Synchronises the device. */
+int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_sym_cb, size_t n_cb,
+                           const int32_t *d_sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
+                           uint8_t *out, size_t cap, size_t *out_len);
+
 /* main.cpp:96-133 with platform "GPU" (RGB2YCbCr, chromaSubsampling, mainEncode,
  * saveEncodedData) : image -> malloc'ed .bin bytes (release with jpegamd_free). */
 int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],

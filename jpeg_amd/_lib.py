@@ -37,6 +37,9 @@ SIGNATURES = {
     "jpegamd_bin_encode": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
                            _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t,
                            _c.POINTER(_c.c_size_t)],
+    "jpegamd_bin_encode_dev": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
+                               _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t,
+                               _c.POINTER(_c.c_size_t)],
     "jpegamd_bin_decode": [_c.c_void_p, _c.c_size_t, _c.c_void_p,
                            _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t),
                            _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t),

@@ -211,6 +211,21 @@ def bin_encode(sym_y, sym_cb, sym_cr, y_rows, y_cols):
     return out[:need.value].tobytes()
 
 
+def bin_encode_dev(sym_y, sym_cb, sym_cr, y_rows, y_cols):
+    """The same container from cuda int32 symbol streams (e.g. the flattened pairs of
+    rle_encode_plane): both passes over the symbols run on the GPU (jpegamd_bin_encode_dev)."""
+    import torch
+    lib = _lib.load()
+    s = [x.reshape(-1) for x in (sym_y, sym_cb, sym_cr)]
+    ptrs = [_dev(x, torch.int32, "bin_encode_dev") if x.numel() else 0 for x in s]
+    need = ctypes.c_size_t(0)
+    args = [v for p, x in zip(ptrs, s) for v in (p, x.numel())] + [int(y_rows), int(y_cols), int(y_rows) // 2, int(y_cols) // 2]
+    lib.jpegamd_bin_encode_dev(*args, None, 0, ctypes.byref(need))  # sizing call
+    out = np.empty(need.value, np.uint8)
+    _lib.check(lib.jpegamd_bin_encode_dev(*args, out.ctypes.data, out.size, ctypes.byref(need)))
+    return out[:need.value].tobytes()
+
+
 def bin_decode(data):
     """.bin bytes -> (dims[6], [sym_y, sym_cb, sym_cr]) (jpegamd_bin_decode; host only)."""
     lib = _lib.load()

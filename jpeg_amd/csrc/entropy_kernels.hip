@@ -1,0 +1,263 @@
+// entropy_kernels.hip -- the reference's entropy stage for one plane with the two passes over
+// the symbols on the device (gfx950):
+//
+//   frequency dictionary   encode_decode.cpp:375-383   counts per symbol, and for the
+//                          dictionary ORDER the index of each symbol's first occurrence
+//   huffman_encode         encode_decode.cpp:458-466 + stringToBitstream :1093-1127
+//                          code lookup and MSB-first bit packing
+//
+// What fixes the bytes of the file -- the std::unordered_map iteration order and the
+// std::priority_queue tie-breaks -- stays on the host (jpegamd_codes_from_order): the device
+// hands it 2 x 64 Ki counters, the host hands back flat (code, length) tables.  The symbols
+// (76 MB for an 8192^2 image) never leave the device; only the payload does.
+//
+//   sym_hist_kernel     counts + first occurrence, window of 2048 hot keys private in LDS
+//   sym_bits_kernel     code-length sum of every workgroup's 2048 symbols
+//   (scan_kernel)       exclusive scan of those sums (64-bit)
+//   sym_pack_kernel     bit offset of every thread's 8 symbols, codes OR-ed into the payload
+//
+// All integer work, bit-exact by construction; tested through jpegamd_compress_image
+// against the reference's files and the oracle's container writer.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "host/entropy_internal.h"
+#include "host_common.h"
+
+namespace {
+
+constexpr int kKeys = 65536; // int16 coefficients and runs 1..64
+constexpr int kWin = 2048;   // keys -1024 .. 1023 are counted in LDS
+constexpr int kThreads = 256;
+constexpr int kPerThread = 8;
+constexpr int kPerWg = kThreads * kPerThread; // 2048 symbols
+
+__global__ __launch_bounds__(kThreads) void sym_hist_kernel(const int32_t *__restrict__ sym, uint32_t n,
+                                                            uint32_t *__restrict__ count,
+                                                            uint32_t *__restrict__ first,
+                                                            uint32_t *__restrict__ bad)
+{
+    __shared__ uint32_t l_count[kWin], l_first[kWin];
+    for (int k = threadIdx.x; k < kWin; k += kThreads)
+        l_count[k] = 0, l_first[k] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const int s = sym[i];
+        if (s < -32768 || s > 32767) {
+            atomicOr(bad, 1u);
+            continue;
+        }
+        const int w = s + kWin / 2;
+        if ((unsigned)w < (unsigned)kWin) {
+            atomicAdd(&l_count[w], 1u);
+            atomicMin(&l_first[w], i);
+        } else {
+            atomicAdd(&count[s + 32768], 1u);
+            atomicMin(&first[s + 32768], i);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kWin; k += kThreads)
+        if (l_count[k]) {
+            atomicAdd(&count[k - kWin / 2 + 32768], l_count[k]);
+            atomicMin(&first[k - kWin / 2 + 32768], l_first[k]);
+        }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// code bits of one workgroup's symbols
+__global__ __launch_bounds__(kThreads) void sym_bits_kernel(const int32_t *__restrict__ sym, uint32_t n,
+                                                            const uint8_t *__restrict__ clen,
+                                                            uint32_t *__restrict__ wg_bits)
+{
+    __shared__ uint32_t part[kThreads / 64];
+    const uint32_t i0 = blockIdx.x * kPerWg + threadIdx.x * kPerThread;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
+        if (i0 + k < n)
+            bits += clen[sym[i0 + k] + 32768];
+    bits = wave_sum(bits);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        wg_bits[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of the workgroups' bit counts: one workgroup walks them 1024 at a time
+__global__ __launch_bounds__(1024) void wg_offsets_kernel(const uint32_t *__restrict__ wg_bits, uint32_t n_wg,
+                                                          unsigned long long *__restrict__ wg_off)
+{
+    __shared__ unsigned long long wave_tot[16];
+    __shared__ unsigned long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_wg; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n_wg ? wg_bits[i] : 0;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(inc, d, 64);
+            if (lane >= d)
+                inc += t;
+        }
+        if (lane == 63)
+            wave_tot[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry_s, all = 0;
+        for (int w = 0; w < 16; ++w) {
+            before += w < wave ? wave_tot[w] : 0;
+            all += wave_tot[w];
+        }
+        if (i < n_wg)
+            wg_off[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            carry_s += all;
+        __syncthreads();
+    }
+}
+
+// Every thread packs its 8 symbols: bit offset = workgroup offset + exclusive scan over the
+// threads, then the codes go MSB-first into 32-bit big-endian words of the (zeroed) payload.
+// Words can be shared with the neighbouring threads, hence atomicOr.
+__global__ __launch_bounds__(kThreads) void sym_pack_kernel(const int32_t *__restrict__ sym, uint32_t n,
+                                                            const uint32_t *__restrict__ cbits,
+                                                            const uint8_t *__restrict__ clen,
+                                                            const unsigned long long *__restrict__ wg_off,
+                                                            uint32_t *__restrict__ payload)
+{
+    __shared__ uint32_t wave_tot[kThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i0 = blockIdx.x * kPerWg + threadIdx.x * kPerThread;
+    uint32_t code[kPerThread], len[kPerThread], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        code[k] = 0, len[k] = 0;
+        if (i0 + k < n) {
+            const int key = sym[i0 + k] + 32768;
+            code[k] = cbits[key], len[k] = clen[key];
+        }
+        mine += len[k];
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d)
+            inc += t;
+    }
+    if (lane == 63)
+        wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < kThreads / 64; ++w)
+        before += w < wave ? wave_tot[w] : 0;
+    unsigned long long pos = wg_off[blockIdx.x] + before + inc - mine; // first bit of this thread
+    // BitWriter (host/bin_container.cpp) with the partial first word as leading zero bits
+    unsigned long long acc = 0;
+    int have = (int)(pos & 31);
+    uint32_t *out = payload + (pos >> 5);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        acc = (acc << len[k]) | code[k];
+        have += (int)len[k];
+        if (have >= 32) {
+            atomicOr(out++, __builtin_bswap32((uint32_t)(acc >> (have - 32))));
+            have -= 32;
+        }
+    }
+    if (have > 0)
+        atomicOr(out, __builtin_bswap32((uint32_t)(acc << (32 - have))));
+}
+
+struct DevMem {
+    void *p = nullptr;
+    ~DevMem()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess ? 0 : 1; }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+} // namespace
+
+int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode &pl)
+{
+    pl.dict.clear();
+    pl.payload.clear();
+    if (n == 0)
+        return 0;
+    if (n >= 0xFFFFFFFFull)
+        return 2;
+    const uint32_t n32 = (uint32_t)n;
+    // counters: count[64 Ki], first[64 Ki], bad
+    DevMem ctr;
+    if (ctr.alloc((2 * kKeys + 1) * sizeof(uint32_t)))
+        return jpegamd_fail("entropy stage: out of device memory");
+    uint32_t *d_count = ctr.as<uint32_t>(), *d_first = d_count + kKeys, *d_bad = d_first + kKeys;
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_count, 0, kKeys * sizeof(uint32_t), nullptr));
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_first, 0xFF, kKeys * sizeof(uint32_t), nullptr));
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), nullptr));
+    const uint32_t hist_grid = std::min<uint32_t>((n32 + kThreads - 1) / kThreads, 2048);
+    hipLaunchKernelGGL(sym_hist_kernel, dim3(hist_grid), dim3(kThreads), 0, nullptr, d_sym, n32, d_count, d_first, d_bad);
+    JPEGAMD_HIPCHK(hipGetLastError());
+    std::vector<uint32_t> h(2 * kKeys + 1);
+    JPEGAMD_HIPCHK(hipMemcpy(h.data(), d_count, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (h[2 * kKeys])
+        return 2; // a symbol outside int16: the host path has the general tables
+    // distinct symbols in first-occurrence order: the insertion sequence of the reference's map
+    std::vector<int> order;
+    for (int k = 0; k < kKeys; ++k)
+        if (h[k])
+            order.push_back(k - 32768);
+    const uint32_t *first = h.data() + kKeys;
+    std::sort(order.begin(), order.end(), [first](int a, int b) { return first[a + 32768] < first[b + 32768]; });
+    std::vector<uint32_t> cbits;
+    std::vector<uint8_t> clen;
+    unsigned long long total_bits = 0;
+    const int rc = jpegamd_codes_from_order(order, h.data(), pl, cbits, clen, total_bits);
+    if (rc)
+        return rc;
+    const size_t bytes = (size_t)((total_bits + 7) / 8);
+    if (bytes > 0x7FFFFFFFu)
+        return jpegamd_fail("bin_encode: payload exceeds the container's int32 length field");
+    pl.payload.resize(bytes);
+    if (bytes == 0)
+        return 0; // a single distinct symbol has the empty code (encode_decode.cpp:444-456)
+    const uint32_t n_wg = (n32 + kPerWg - 1) / kPerWg;
+    const size_t words = (bytes + 3) / 4 + 2;
+    DevMem tab, sums, offs, out;
+    if (tab.alloc(kKeys * 5) || sums.alloc(n_wg * sizeof(uint32_t)) || offs.alloc(n_wg * sizeof(unsigned long long)) ||
+        out.alloc(words * 4))
+        return jpegamd_fail("entropy stage: out of device memory");
+    uint32_t *d_cbits = tab.as<uint32_t>();
+    uint8_t *d_clen = reinterpret_cast<uint8_t *>(d_cbits + kKeys);
+    JPEGAMD_HIPCHK(hipMemcpy(d_cbits, cbits.data(), kKeys * 4, hipMemcpyHostToDevice));
+    JPEGAMD_HIPCHK(hipMemcpy(d_clen, clen.data(), kKeys, hipMemcpyHostToDevice));
+    JPEGAMD_HIPCHK(hipMemsetAsync(out.p, 0, words * 4, nullptr));
+    hipLaunchKernelGGL(sym_bits_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, d_sym, n32, d_clen, sums.as<uint32_t>());
+    hipLaunchKernelGGL(wg_offsets_kernel, dim3(1), dim3(1024), 0, nullptr, sums.as<uint32_t>(), n_wg,
+                       offs.as<unsigned long long>());
+    hipLaunchKernelGGL(sym_pack_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, d_sym, n32, d_cbits, d_clen,
+                       offs.as<unsigned long long>(), out.as<uint32_t>());
+    JPEGAMD_HIPCHK(hipGetLastError());
+    JPEGAMD_HIPCHK(hipMemcpy(pl.payload.data(), out.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}

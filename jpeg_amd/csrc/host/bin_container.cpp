@@ -28,6 +28,7 @@
 
 #include "../../../include/jpeg_amd.h"
 #include "../host_common.h"
+#include "entropy_internal.h"
 
 namespace {
 
@@ -124,10 +125,7 @@ struct BitWriter { // stringToBitstream's layout (:1093-1127): MSB first, last b
     }
 };
 
-struct Plane {
-    std::vector<std::pair<int, int>> dict; // (key, frequency) in unordered_map iteration order
-    std::vector<uint8_t> payload;
-};
+typedef JpegamdPlaneCode Plane;
 
 constexpr int kDense = 1 << 17; // symbols in [-65536, 65535] use flat tables
 
@@ -306,20 +304,47 @@ int get_i32(const uint8_t *p)
 
 } // namespace
 
-extern "C" {
+int jpegamd_host_encode_plane(const int32_t *sym, size_t n, JpegamdPlaneCode &pl) { return encode_plane(sym, n, pl); }
 
-int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, size_t n_cb,
-                       const int32_t *sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
-                       uint8_t *out, size_t cap, size_t *out_len)
+int jpegamd_codes_from_order(const std::vector<int> &order, const uint32_t *count, JpegamdPlaneCode &pl,
+                             std::vector<uint32_t> &cbits, std::vector<uint8_t> &clen, unsigned long long &total_bits)
 {
-    if (!out_len || (!sym_y && n_y) || (!sym_cb && n_cb) || (!sym_cr && n_cr))
-        return fail("bin_encode: null pointer");
-    Plane pl[3];
-    if (encode_plane(sym_y, n_y, pl[0]) || encode_plane(sym_cb, n_cb, pl[1]) || encode_plane(sym_cr, n_cr, pl[2]))
-        return 1;
+    std::unordered_map<int, int> freq; // the reference's container, same insertion sequence (:375-383)
+    for (int s : order) {
+        if (s == kInternal)
+            return fail("bin_encode: symbol 99999 collides with the reference's internal-node marker");
+        freq[s] = (int)count[s + 32768];
+    }
+    pl.dict.assign(freq.begin(), freq.end());
+    Tree t;
+    build_tree(pl.dict, t);
+    std::unordered_map<int, Code> codes;
+    assign_codes(t, codes);
+    cbits.assign(65536, 0);
+    clen.assign(65536, 0);
+    total_bits = 0;
+    for (const auto &kv : codes) {
+        if (kv.second.bits.size() > 32)
+            return 2;
+        uint32_t v = 0;
+        for (uint8_t b : kv.second.bits)
+            v = (v << 1) | b;
+        cbits[kv.first + 32768] = v;
+        clen[kv.first + 32768] = (uint8_t)kv.second.bits.size();
+        total_bits += (unsigned long long)kv.second.bits.size() * count[kv.first + 32768];
+    }
+    return 0;
+}
+
+int jpegamd_bin_assemble(const JpegamdPlaneCode (&pl)[3], int y_rows, int y_cols, int c_rows, int c_cols, uint8_t *out,
+                         size_t cap, size_t *out_len)
+{
     size_t need = 9 * 4 + 3 * 4;
-    for (const Plane &p : pl)
+    for (const Plane &p : pl) {
+        if (p.payload.size() > 0x7FFFFFFFu)
+            return fail("bin_encode: payload exceeds the container's int32 length field");
         need += p.payload.size() + 8 * p.dict.size();
+    }
     *out_len = need;
     if (!out || cap < need)
         return fail("bin_encode: output buffer too small (the size needed is in *out_len)");
@@ -341,6 +366,20 @@ int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, 
         for (const auto &kv : p.dict)
             put_i32(w, kv.first), put_i32(w, kv.second);
     return 0;
+}
+
+extern "C" {
+
+int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, size_t n_cb,
+                       const int32_t *sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
+                       uint8_t *out, size_t cap, size_t *out_len)
+{
+    if (!out_len || (!sym_y && n_y) || (!sym_cb && n_cb) || (!sym_cr && n_cr))
+        return fail("bin_encode: null pointer");
+    Plane pl[3];
+    if (encode_plane(sym_y, n_y, pl[0]) || encode_plane(sym_cb, n_cb, pl[1]) || encode_plane(sym_cr, n_cr, pl[2]))
+        return 1;
+    return jpegamd_bin_assemble(pl, y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
 }
 
 int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],

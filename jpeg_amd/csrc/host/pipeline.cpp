@@ -11,6 +11,7 @@
 
 #include "../../../include/jpeg_amd.h"
 #include "../host_common.h"
+#include "entropy_internal.h"
 
 namespace {
 
@@ -42,8 +43,16 @@ struct HostSymbols {
     }
 };
 
-// run-length pairs of one device coefficient plane, copied to the host
-int plane_symbols(const int16_t *d_coef, size_t nb, HostSymbols &sym)
+// JPEGAMD_ENTROPY=host keeps both passes of the entropy stage on the host (the first
+// implementation, still the path for inputs the device tables do not cover)
+bool entropy_on_host()
+{
+    const char *e = std::getenv("JPEGAMD_ENTROPY");
+    return e && std::strcmp(e, "host") == 0;
+}
+
+// run-length stage and entropy stage of one device coefficient plane
+int plane_code(const int16_t *d_coef, size_t nb, JpegamdPlaneCode &code)
 {
     DevMem work, offs, pairs;
     const size_t wbytes = jpegamd_rle_workspace_bytes(nb);
@@ -63,11 +72,17 @@ int plane_symbols(const int16_t *d_coef, size_t nb, HostSymbols &sym)
         uint32_t total = 0;
         JPEGAMD_HIPCHK(hipMemcpy(&total, offs.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost));
         if (total <= cap) {
+            if (!entropy_on_host()) {
+                const int rc = jpegamd_device_encode_plane(pairs.as<int32_t>(), (size_t)total * 2, code);
+                if (rc != 2)
+                    return rc;
+            }
+            HostSymbols sym; // the host path: the pairs are the memory of the reference's std::vector<int>
             if (!sym.resize((size_t)total * 2))
                 return jpegamd_fail("compress_image: out of host memory");
             if (total && jpegamd_staged_copy_linear(pairs.p, sym.data(), (size_t)total * 8, false))
                 return 1;
-            return 0;
+            return jpegamd_host_encode_plane(sym.data(), sym.size(), code);
         }
         cap = total;
     }
@@ -103,6 +118,32 @@ int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]
     return 0;
 }
 
+int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_sym_cb, size_t n_cb,
+                           const int32_t *d_sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
+                           uint8_t *out, size_t cap, size_t *out_len)
+{
+    if (!out_len || (!d_sym_y && n_y) || (!d_sym_cb && n_cb) || (!d_sym_cr && n_cr))
+        return jpegamd_fail("bin_encode_dev: null pointer");
+    const int32_t *d_sym[3] = {d_sym_y, d_sym_cb, d_sym_cr};
+    const size_t n[3] = {n_y, n_cb, n_cr};
+    JpegamdPlaneCode code[3];
+    JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the symbols may come from kernels on other streams
+    for (int k = 0; k < 3; ++k) {
+        int rc = entropy_on_host() ? 2 : jpegamd_device_encode_plane(d_sym[k], n[k], code[k]);
+        if (rc == 2) { // general tables (symbols beyond int16, codes beyond 32 bits): the host path
+            HostSymbols sym;
+            if (!sym.resize(n[k]))
+                return jpegamd_fail("bin_encode_dev: out of host memory");
+            if (n[k] && jpegamd_staged_copy_linear(const_cast<int32_t *>(d_sym[k]), sym.data(), n[k] * 4, false))
+                return 1;
+            rc = jpegamd_host_encode_plane(sym.data(), n[k], code[k]);
+        }
+        if (rc)
+            return 1;
+    }
+    return jpegamd_bin_assemble(code, y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
+}
+
 int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
                            const int32_t q_chroma[64], uint8_t **bin, size_t *bin_len)
 {
@@ -120,18 +161,16 @@ int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride
     if (jpegamd_encode_image_dev(d_bgr.as<uint8_t>(), rows, cols, (size_t)cols * 3, q_luma, q_chroma,
                                  d_y.as<int16_t>(), d_cb.as<int16_t>(), d_cr.as<int16_t>(), nullptr))
         return 1;
-    HostSymbols sy, scb, scr;
-    if (plane_symbols(d_y.as<int16_t>(), nby, sy) || plane_symbols(d_cb.as<int16_t>(), nbc, scb) ||
-        plane_symbols(d_cr.as<int16_t>(), nbc, scr))
+    JpegamdPlaneCode code[3];
+    if (plane_code(d_y.as<int16_t>(), nby, code[0]) || plane_code(d_cb.as<int16_t>(), nbc, code[1]) ||
+        plane_code(d_cr.as<int16_t>(), nbc, code[2]))
         return 1;
     size_t need = 0;
-    (void)jpegamd_bin_encode(sy.data(), sy.size(), scb.data(), scb.size(), scr.data(), scr.size(), rows, cols,
-                             rows / 2, cols / 2, nullptr, 0, &need); // sizing call
+    (void)jpegamd_bin_assemble(code, rows, cols, rows / 2, cols / 2, nullptr, 0, &need); // sizing call
     uint8_t *buf = static_cast<uint8_t *>(std::malloc(need ? need : 1));
     if (!buf)
         return jpegamd_fail("compress_image: out of host memory");
-    if (jpegamd_bin_encode(sy.data(), sy.size(), scb.data(), scb.size(), scr.data(), scr.size(), rows, cols,
-                           rows / 2, cols / 2, buf, need, &need)) {
+    if (jpegamd_bin_assemble(code, rows, cols, rows / 2, cols / 2, buf, need, &need)) {
         std::free(buf);
         return 1;
     }
