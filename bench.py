@@ -26,11 +26,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 BYTES_PER_PIXEL_ENC = 6.0  # 3 B BGR read + 1.5 coefficients x 2 B written
 BYTES_PER_PIXEL_DEC = 6.0  # 3 B coefficients read + 3 B BGR written
 # HBM bytes per launch at 8192^2 QF=50 from rocprofv3 PMC passes (separate --pmc runs of
-# tools/prof_run.py, profiles/r01_f_pmc_hbm_traffic.txt): FETCH_SIZE x 2 (the gfx950
+# tools/prof_run.py, profiles/r01_h_pmc_hbm_traffic.txt): FETCH_SIZE x 2 (the gfx950
 # correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both reported in KiB.
 MEASURED_TRAFFIC = {
-    (8192, 8192, 50): {"encode_image_kernel": (98562 * 2 + 196608) * 1024,
-                       "decode_image_kernel": (98538 * 2 + 196619) * 1024},
+    (8192, 8192, 50): {"encode_image_kernel": (100236 * 2 + 196608) * 1024,
+                       "decode_image_kernel": (98544 * 2 + 196649) * 1024},
 }
 
 
@@ -95,9 +95,23 @@ def main():
                   for n in ((rows // 8) * (cols // 8), (rows // 16) * (cols // 16), (rows // 16) * (cols // 16)))
     rec = torch.empty_like(bgr)
 
+    # The two launches of a step go straight through the C ABI with their arguments marshalled
+    # once: the Python wrappers (tensor checks, table conversion) cost more per call than the
+    # GPU needs per kernel and would leave it idle between launches.
+    import ctypes
+    import numpy as np
+    from jpeg_amd import _lib
+    lib = _lib.load()
+    ql32, qc32 = (np.ascontiguousarray(np.asarray(t, np.int32).reshape(64)) for t in (qy, qc))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    enc_args = (bgr.data_ptr(), rows, cols, cols * 3, ql32.ctypes.data, qc32.ctypes.data,
+                coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), stream)
+    dec_args = (coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), rows, cols,
+                ql32.ctypes.data, qc32.ctypes.data, rec.data_ptr(), cols * 3, stream)
+
     def step():
-        jpeg_amd.encode_image(bgr, qy, qc, out=coefs)
-        jpeg_amd.decode_image(*coefs, rows, cols, qy, qc, out=rec)
+        _lib.check(lib.jpegamd_encode_image_dev(*enc_args))
+        _lib.check(lib.jpegamd_decode_image_dev(*dec_args))
 
     for _ in range(args.warmup):
         step()

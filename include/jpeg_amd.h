@@ -158,9 +158,10 @@ void jpegamd_free(void *p);
  * (row-major 8x8, clamped to 1..255); non-zero for a quality outside that range. */
 int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]);
 
-/* Times `iters` back-to-back launches of encode followed by decode on `stream`
- * with HIP events recorded on that same stream; writes the mean milliseconds
- * per launch of each kernel.  Used by bench.py for the roofline figures. */
+/* Times `iters` steps of encode followed by decode on `stream`, in that alternating
+ * sequence, with HIP events recorded on that same stream between every two launches;
+ * writes the mean milliseconds per launch of each kernel.  Used by bench.py for the
+ * roofline figures. */
 int jpegamd_time_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride,
                            const int32_t q_luma[64], const int32_t q_chroma[64],
                            int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr,

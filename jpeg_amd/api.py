@@ -149,8 +149,8 @@ def dequant_idct_blocks(coef, q):
 
 
 def time_image(bgr, coefs, bgr_out, q_luma, q_chroma, iters, stream=None):
-    """HIP-event timing of `iters` encode launches then `iters` decode launches
-    on the stream they run on; returns (enc_ms, dec_ms) per launch."""
+    """HIP-event timing of `iters` steps (encode, decode, encode, ...) on the stream they run
+    on, one event between every two launches; returns the mean (enc_ms, dec_ms) per launch."""
     import torch
     rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
     ql, pl = _q(q_luma)
