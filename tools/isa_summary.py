@@ -3,7 +3,7 @@ import re
 import sys
 from collections import Counter
 
-s = open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/jpeg_kernels.s").read()
+s = "".join(open(f).read() for f in (sys.argv[1:] or ["/tmp/jpeg_kernels.s", "/tmp/encode_variants.s"]))
 for name in ("encode_image_xdl_kernel", "encode_image_mfma_kernel", "encode_image_kernel", "decode_image_kernel"):
     sym = re.search(r"^(_ZN\S*\d+" + name + r"E\S*):", s, re.M).group(1)
     blk = re.search(r"\.amdhsa_kernel " + re.escape(sym) + r".*?\.end_amdhsa_kernel", s, re.S).group(0)
