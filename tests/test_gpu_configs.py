@@ -170,3 +170,31 @@ def test_config5_full_size_quality(gpu, orc, qf):
     _strip_parity(orc, bgr, coefs, rec, qy, qc, (0, 129, 255), f"QF={qf}")
     again = jpeg_amd.encode_image(bgr, qy, qc)
     assert all(torch.equal(x, y) for x, y in zip(coefs, again))  # deterministic
+
+
+def test_device_entry_points_can_be_captured_in_a_hip_graph(gpu):
+    """the _dev entry points allocate nothing and never synchronise, so a caller may record
+    them into a HIP graph and replay it (serving loops do); results equal the eager ones"""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    rows, cols = 64, 1040
+    qy, qc = jpeg_amd.quality_tables(60)
+    img = synth_image(rows, cols, 5, "photo", device=gpu)
+    eager = jpeg_amd.encode_image(img, qy, qc)
+    eager_rec = jpeg_amd.decode_image(*eager, rows, cols, qy, qc)
+    coefs = tuple(torch.zeros_like(c) for c in eager)
+    rec = torch.zeros_like(eager_rec)
+    side = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(side):  # warm-up on the capture stream, as torch asks
+        jpeg_amd.encode_image(img, qy, qc, out=coefs, stream=side.cuda_stream)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        jpeg_amd.encode_image(img, qy, qc, out=coefs, stream=side.cuda_stream)
+        jpeg_amd.decode_image(*coefs, rows, cols, qy, qc, out=rec, stream=side.cuda_stream)
+    for c in coefs:
+        c.zero_()
+    rec.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(coefs, eager)) and torch.equal(rec, eager_rec)
