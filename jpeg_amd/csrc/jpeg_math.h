@@ -536,8 +536,19 @@ JM_HD bool jm_fwd_any_tie(const JmFwdTies &t)
 
 // Exact ties: the value is k + 0.5 as a rational; the reference's double sequence
 // (encode_decode.cpp:58-63, one rounding per operation, no contraction) lands on,
-// above or below it, and round() goes up unless it is below.  cb/cr stay centred
-// (value - 128); 256 wraps to 0, i.e. -128 centred.
+// above or below it, and round() goes up unless it is below.  The fast path has rounded
+// the tie UP, so its own value names the tie: "up - 0.5".  (A Cb candidate that is no
+// exact tie compares at least 1e-4 above "its rounded value - 0.5" and stays as it is.)
+// Exact products (0.5 x, and 128 + 0.5 x) are folded into the neighbouring addition: one
+// rounding either way.  cb/cr stay centred (value - 128); 256 wraps to 0, i.e. -128 centred.
+JM_HD double jm_fma64(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return fma(a, b, c);
+#endif
+}
 JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, float &uy, float &cb, float &cr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -550,23 +561,21 @@ JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, f
         double v = 0.299 * d0; // 0.0 + x is exact
         v = v + 0.587 * d1;
         v = v + 0.114 * d2;
-        float k = ((t.sy - 0.5f) + JM_MAGIC) - JM_MAGIC;
-        uy = (v >= (double)k + 0.5 ? k + 1.0f : k) + JM_MAGIC;
+        const float up = uy - JM_MAGIC;
+        uy = v < (double)up - 0.5 ? uy - 1.0f : uy;
     }
     if (t.rb < JM_TIE_B) {
         double v = 128.0 + -0.1687 * d0;
         v = v + -0.3313 * d1;
-        v = v + 0.5 * d2;
-        float k = ((t.sb - 0.5f) + JM_MAGIC) - JM_MAGIC; // centred floor
-        cb = v >= (double)k + 128.5 ? k + 1.0f : k;
+        v = jm_fma64(0.5, d2, v);
+        cb = v < (double)cb + 127.5 ? cb - 1.0f : cb;
         cb = cb == 128.0f ? -128.0f : cb;
     }
     if (t.rr < JM_TIE_A) {
-        double v = 128.0 + 0.5 * d0;
+        double v = jm_fma64(0.5, d0, 128.0);
         v = v + -0.4187 * d1;
         v = v + -0.0813 * d2;
-        float k = ((t.sr - 0.5f) + JM_MAGIC) - JM_MAGIC;
-        cr = v >= (double)k + 128.5 ? k + 1.0f : k;
+        cr = v < (double)cr + 127.5 ? cr - 1.0f : cr;
         cr = cr == 128.0f ? -128.0f : cr;
     }
 }
