@@ -75,15 +75,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # One rank per GPU over RCCL.  Only when there are fewer GPUs than ranks (a rehearsal of
+    # the rank logic on a one-GPU box) do ranks share a device, and then the two tiny
+    # control-plane collectives go through gloo on host tensors: RCCL refuses two ranks on one GPU.
+    shared = world > torch.cuda.device_count()
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
     jpeg_amd.init(local)
     dev = torch.device("cuda", local)
 
@@ -129,7 +136,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -160,7 +167,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"synthetic {rows}x{cols} RGB QF={args.quality} encode+decode, "
                                    f"one image per GPU resident in HBM (BASELINE configs[1])",
-                       "images_per_step_per_gpu": 1, "parallelism": f"batch x{world} (whole images per rank)"},
+                       "images_per_step_per_gpu": 1, "parallelism": f"batch x{world} (whole images per rank)"
+                       + (", REHEARSAL: ranks share one GPU" if shared else "")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": MEASURED_TRAFFIC.get((rows, cols, args.quality), {}).get(dominant),
