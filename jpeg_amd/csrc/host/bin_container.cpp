@@ -19,6 +19,7 @@
 // packed MSB-first as they are produced (:1093-1127 give the byte layout).
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 #include <thread>
@@ -152,6 +153,193 @@ template <class F> void parallel_chunks(unsigned nt, F f) // f(chunk index)
     for (auto &t : th)
         t.join();
 }
+
+// ---------------------------------------------------------------- plane decoder
+// huffman_decode (:468-482) walks the tree bit by bit over the whole payload.  Here a 12-bit
+// window resolves up to four whole codes per step (the average code is 2-3 bits); a code
+// longer than the window continues bit by bit from the node the window reaches, so the
+// symbol sequence is exactly the bit-serial walk's.
+//
+// A plane's bit stream has no restart points, but prefix codes resynchronise: a decoder
+// started at a wrong bit position falls into step with the true one after a few codes.  Large
+// planes are therefore decoded by several threads.  Pass 1: every thread decodes its chunk
+// from the chunk's first bit as if a code began there, only counting, and notes where its
+// first kHeads codes begin.  Stitch (sequential, short): from the true end of the previous
+// chunk the true decoding is continued code by code until it reaches a position the next
+// thread has noted -- from there on that thread's codes ARE the true ones, which gives the
+// exact bit position and symbol offset of a region per thread.  Pass 2: every thread decodes
+// its region into place.  A chunk that never falls into step (possible, never seen) is
+// simply decoded as part of its predecessor's region.
+class PlaneDecoder {
+  public:
+    PlaneDecoder(const Tree &t, const uint8_t *payload, unsigned long long nbits) : t_(t), p_(payload), nbits_(nbits)
+    {
+        win_.resize(1u << kWin);
+        for (int v = 0; v < (1 << kWin); ++v) {
+            Win &w = win_[v];
+            w = Win{};
+            int cur = t.root, used = 0;
+            while (used < kWin) {
+                cur = ((v >> (kWin - 1 - used)) & 1) ? t.right[cur] : t.left[cur];
+                ++used;
+                if (t.leaf(cur)) {
+                    w.sym[w.count++] = t.value[cur];
+                    w.used = (uint8_t)used;
+                    cur = t.root;
+                    if (w.count == kMaxSym)
+                        break;
+                }
+            }
+            w.node = cur;
+            if (w.count == 0)
+                w.used = kWin;
+        }
+    }
+
+    // all symbols of the plane; returns their number (more than cap: the buffer was too small,
+    // only the first cap were written)
+    size_t decode(int32_t *out, size_t cap, unsigned threads)
+    {
+        const unsigned long long chunk_bits = threads > 1 ? (nbits_ / threads) & ~7ull : 0;
+        if (threads <= 1 || chunk_bits < 64)
+            return run(0, nbits_, false, out, cap, 0, nullptr).n;
+        // pass 1
+        struct Chunk {
+            std::vector<unsigned long long> heads; // where its first codes begin
+            unsigned long long end = 0;            // first code boundary at or after the next chunk's start
+            size_t count = 0;
+        };
+        std::vector<Chunk> ch(threads);
+        parallel_chunks(threads, [&](unsigned k) {
+            const unsigned long long a = k * chunk_bits, b = k + 1 == threads ? nbits_ : (k + 1) * chunk_bits;
+            const Progress r = run(a, b, false, nullptr, 0, 0, &ch[k].heads);
+            ch[k].end = r.pos, ch[k].count = r.n;
+        });
+        // stitch: region k = [start[k], start[k + 1]) holds the symbols first[k] .. first[k + 1] - 1
+        std::vector<unsigned long long> start(threads + 1, nbits_);
+        std::vector<size_t> first(threads + 1, 0);
+        start[0] = 0;
+        unsigned long long pos = ch[0].end; // true position, always a code boundary
+        size_t n = ch[0].count;             // symbols before pos
+        bool stream_done = pos >= nbits_;
+        for (unsigned k = 1; k < threads; ++k) {
+            const Chunk &c = ch[k];
+            const unsigned long long chunk_end = k + 1 == threads ? nbits_ : (k + 1) * chunk_bits;
+            size_t i = 0;
+            bool in_step = false;
+            while (!stream_done) {
+                while (i < c.heads.size() && c.heads[i] < pos)
+                    ++i;
+                if (i < c.heads.size() && c.heads[i] == pos) {
+                    in_step = true;
+                    break;
+                }
+                if (i == c.heads.size() || pos >= chunk_end)
+                    break; // beyond what the thread noted: treat the chunk as part of this region
+                const Progress r = run(pos, nbits_, false, nullptr, 0, 0, nullptr, 1); // one true code
+                if (r.n == 0)
+                    stream_done = true; // ran out of bits inside a code
+                pos = r.pos, n += r.n;
+            }
+            if (in_step) {
+                start[k] = pos, first[k] = n;
+                n += c.count - i;
+                pos = c.end;
+                stream_done = pos >= nbits_;
+            } else {
+                start[k] = ~0ull; // empty region
+                if (!stream_done && pos < chunk_end) { // the rare sequential stretch
+                    const Progress r = run(pos, chunk_end, false, nullptr, 0, 0, nullptr);
+                    n += r.n, pos = r.pos;
+                    stream_done = pos >= nbits_ || r.stalled;
+                }
+            }
+        }
+        // empty regions take their successor's start
+        first[threads] = n;
+        for (unsigned k = threads; k-- > 1;)
+            if (start[k] == ~0ull)
+                start[k] = start[k + 1], first[k] = first[k + 1];
+        if (!out)
+            return n;
+        // pass 2
+        parallel_chunks(threads, [&](unsigned k) {
+            if (start[k] < start[k + 1])
+                // (cap: never past the region's own symbols -- the window writes four slots at a time)
+                run(start[k], start[k + 1], start[k + 1] < nbits_, out, std::min(cap, first[k + 1]), first[k], nullptr);
+        });
+        return n;
+    }
+
+  private:
+    static constexpr int kWin = 12, kMaxSym = 4;
+    static constexpr size_t kHeads = 512;
+    struct Win {
+        int32_t sym[kMaxSym]; // values of the whole codes found, in order
+        int32_t node;         // count == 0: the inner node reached after kWin bits
+        uint8_t count, used;  // whole codes found / bits they take (kWin if count == 0)
+    };
+    struct Progress {
+        unsigned long long pos; // a code boundary (or the end of the stream)
+        size_t n;               // symbols found by this call
+        bool stalled;           // the stream ended inside a code
+    };
+    const Tree &t_;
+    const uint8_t *p_;
+    const unsigned long long nbits_;
+    std::vector<Win> win_;
+
+    int bit_at(unsigned long long i) const { return (p_[i >> 3] >> (7 - (i & 7))) & 1; }
+
+    // Decodes codes from the boundary `pos` while pos < stop.  exact: `stop` is a true boundary
+    // and no code beyond it may be consumed (the window is used only where it cannot cross it).
+    // heads: note where the first kHeads codes begin (those go one code at a time).
+    // Symbols go to out[n0 + ...] while that index is below cap (out may be null: counting).
+    Progress run(unsigned long long pos, unsigned long long stop, bool exact, int32_t *out, size_t cap, size_t n0,
+                 std::vector<unsigned long long> *heads, size_t max_codes = ~(size_t)0) const
+    {
+        size_t n = 0;
+        const bool single = max_codes != ~(size_t)0;
+        while (pos < stop && n < max_codes) {
+            int cur = t_.root;
+            const bool noting = heads && heads->size() < kHeads;
+            if (noting)
+                heads->push_back(pos);
+            if (!noting && !single && pos + 64 <= nbits_ && (!exact || pos + kWin <= stop)) {
+                uint64_t bits;
+                std::memcpy(&bits, p_ + (pos >> 3), 8);
+                bits = __builtin_bswap64(bits) << (pos & 7);
+                const Win &w = win_[(size_t)(bits >> (64 - kWin))];
+                pos += w.used;
+                if (w.count) {
+                    const size_t at = n0 + n;
+                    if (at + kMaxSym <= cap) { // room for all four slots: no per-symbol test
+                        for (int i = 0; i < kMaxSym; ++i)
+                            out[at + i] = w.sym[i];
+                    } else {
+                        for (int i = 0; i < w.count; ++i)
+                            if (at + i < cap)
+                                out[at + i] = w.sym[i];
+                    }
+                    n += w.count;
+                    continue;
+                }
+                cur = w.node;
+            }
+            while (!t_.leaf(cur) && pos < nbits_)
+                cur = bit_at(pos++) ? t_.right[cur] : t_.left[cur];
+            if (!t_.leaf(cur)) {
+                if (noting)
+                    heads->pop_back();
+                return {pos, n, true}; // ran out of bits inside a code: the reference emits nothing for it either
+            }
+            if (n0 + n < cap)
+                out[n0 + n] = t_.value[cur];
+            ++n;
+        }
+        return {pos, n, false};
+    }
+};
 
 int encode_plane(const int32_t *sym, size_t n, Plane &pl)
 {
@@ -418,6 +606,22 @@ int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
         dict_off[c] = off;
         off += (size_t)dsz[c] * 8;
     }
+    // Threads per plane (PlaneDecoder): in proportion to the payloads, 16 in all at most, none
+    // extra for less than 64 KiB of payload each (JPEGAMD_DECODE_CHUNK_BYTES overrides that
+    // size; the tests use it to cut small files into many chunks).
+    unsigned chunk_threads[3] = {1, 1, 1};
+    {
+        size_t min_chunk = 1u << 16;
+        if (const char *e = getenv("JPEGAMD_DECODE_CHUNK_BYTES"))
+            min_chunk = (size_t)std::max(8L, atol(e));
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t budget = std::min(hw, 16u);
+        const size_t total = (size_t)lens[0] + (size_t)lens[1] + (size_t)lens[2];
+        for (int c = 0; c < 3 && total > 0; ++c) {
+            const size_t share = std::max<size_t>(1, budget * (size_t)lens[c] / total);
+            chunk_threads[c] = (unsigned)std::max<size_t>(1, std::min(share, (size_t)lens[c] / min_chunk));
+        }
+    }
     // The three planes are independent streams: one thread each when the file is large.
     // Workers only report a status; the message is set on the calling thread.
     enum { kOk = 0, kNoCode = 1, kTooSmall = 2 };
@@ -436,70 +640,8 @@ int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
             }
             // bitstreamToString(len * 8) + huffman_decode (:1261-1263, :468-482): every bit of
             // every byte, the zero padding included -- it may yield spurious trailing symbols.
-            // A 12-bit window resolves up to four whole codes in one step (the average code is
-            // 2-3 bits); a code longer than the window continues bit by bit from the node the
-            // window reaches, so the symbol sequence is exactly the bit-serial walk's.
-            constexpr int kWin = 12, kMaxSym = 4;
-            struct Win {
-                int32_t sym[kMaxSym]; // values of the whole codes found, in order
-                int32_t node;         // count == 0: the inner node reached after kWin bits
-                uint8_t count, used;  // whole codes found / bits they take (kWin if count == 0)
-            };
-            std::vector<Win> win(1 << kWin);
-            for (int v = 0; v < (1 << kWin); ++v) {
-                Win &w = win[v];
-                w = Win{};
-                int cur = t.root, used = 0;
-                while (used < kWin) {
-                    cur = ((v >> (kWin - 1 - used)) & 1) ? t.right[cur] : t.left[cur];
-                    ++used;
-                    if (t.leaf(cur)) {
-                        w.sym[w.count++] = t.value[cur];
-                        w.used = (uint8_t)used;
-                        cur = t.root;
-                        if (w.count == kMaxSym)
-                            break;
-                    }
-                }
-                w.node = cur;
-                if (w.count == 0)
-                    w.used = kWin;
-            }
-            const unsigned long long nbits = (unsigned long long)lens[c] * 8;
-            auto bit_at = [&](unsigned long long i) { return (payload[c][i >> 3] >> (7 - (i & 7))) & 1; };
-            int32_t *out = outs[c];
-            const size_t cap = out ? caps[c] : 0;
-            unsigned long long pos = 0;
-            while (pos < nbits) {
-                int cur = t.root;
-                if (pos + 64 <= nbits) { // a whole window (and then some) is available
-                    uint64_t bits;
-                    std::memcpy(&bits, payload[c] + (pos >> 3), 8);
-                    bits = __builtin_bswap64(bits) << (pos & 7);
-                    const Win &w = win[(size_t)(bits >> (64 - kWin))];
-                    pos += w.used;
-                    if (w.count) {
-                        if (n + kMaxSym <= cap) { // room for all four slots: no per-symbol test
-                            for (int i = 0; i < kMaxSym; ++i)
-                                out[n + i] = w.sym[i];
-                        } else {
-                            for (int i = 0; i < w.count; ++i)
-                                if (n + i < cap)
-                                    out[n + i] = w.sym[i];
-                        }
-                        n += w.count;
-                        continue;
-                    }
-                    cur = w.node;
-                }
-                while (!t.leaf(cur) && pos < nbits)
-                    cur = bit_at(pos++) ? t.right[cur] : t.left[cur];
-                if (!t.leaf(cur))
-                    break; // ran out of bits inside a code: the reference emits nothing for it either
-                if (n < cap)
-                    out[n] = t.value[cur];
-                ++n;
-            }
+            PlaneDecoder dec(t, payload[c], (unsigned long long)lens[c] * 8);
+            n = dec.decode(outs[c], outs[c] ? caps[c] : 0, chunk_threads[c]);
         }
         *ns[c] = n; // the count found; more than cap means the caller's buffer was too small
         if (n > caps[c])
