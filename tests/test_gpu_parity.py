@@ -131,6 +131,32 @@ def test_image_vs_oracle(gpu, orc, model, kind, seed, rows, cols, qf):
         assert (coefs[1] == 0).all() and (coefs[2] == 0).all()
 
 
+def test_image_of_exact_ties_only(gpu, orc, model):
+    """Every pixel an exact x.5 tie of the forward colour transform (all 16 782 Y ties and
+    Cb and Cr ties of both directions, the two 256 -> 0 wraps among them): the encoder's
+    re-evaluation path runs for every lane of every test, in both rows, and the result must
+    still be the oracle's colour planes through the model transform, bit for bit (QF = 100:
+    a wrong colour byte changes coefficients)."""
+    import jpeg_amd
+    v = np.arange(256, dtype=np.int64)
+    p0, p1, p2 = np.meshgrid(v, v, v, indexing="ij")
+    ties = ((299 * p0 + 587 * p1 + 114 * p2) % 1000 == 500) | ((p0 == p1) & ((p2 - p0) % 2 == 1)) \
+        | ((p1 == p2) & ((p0 - p1) % 2 == 1))
+    tri = np.stack(np.nonzero(ties), -1).astype(np.uint8)
+    assert [255, 0, 0] in tri.tolist() and [0, 0, 255] in tri.tolist()
+    rows, cols = 128, 640
+    rng = np.random.default_rng(99)
+    wraps = np.array([[255, 0, 0], [0, 0, 255]], np.uint8)
+    pick = np.concatenate([wraps, tri[rng.permutation(tri.shape[0])[:rows * cols - 2]]])
+    bgr = np.ascontiguousarray(pick[rng.permutation(rows * cols)].reshape(rows, cols, 3))
+    qy, qc = jpeg_amd.quality_tables(100)
+    coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)]
+    for g, m in zip(coefs, _model_image(model, orc, bgr, qy, qc)):
+        assert np.array_equal(g, m)
+    for g, w, n in zip(coefs, orc.encode_image(bgr, qy, qc), "Y Cb Cr".split()):
+        _check_coef(g, w, f"ties {n}")
+
+
 def test_matrix_core_encoder_variant(gpu, orc, model, monkeypatch):
     """JPEGAMD_TRANSFORM=mfma: the opt-in encoder whose DCT runs as v_mfma_f32_16x16x4_f32
     chains.  An f32 MFMA is a k-ordered fma chain, so it must equal the host replay
