@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <queue>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <utility>
@@ -147,9 +148,16 @@ template <class F> void parallel_chunks(unsigned nt, F f) // f(chunk index)
         return;
     }
     std::vector<std::thread> th;
-    for (unsigned i = 1; i < nt; ++i)
-        th.emplace_back(f, i);
+    th.reserve(nt - 1);
+    unsigned started = 1;
+    try {
+        for (; started < nt; ++started)
+            th.emplace_back(f, started);
+    } catch (const std::system_error &) { // no more threads to be had: the rest runs here
+    }
     f(0u);
+    for (unsigned i = started; i < nt; ++i)
+        f(i);
     for (auto &t : th)
         t.join();
 }
@@ -648,10 +656,7 @@ int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
             status[c] = kTooSmall;
     };
     if ((size_t)lens[0] + (size_t)lens[1] + (size_t)lens[2] >= (1u << 18)) {
-        std::thread cb(decode_plane, 1), cr(decode_plane, 2);
-        decode_plane(0);
-        cb.join();
-        cr.join();
+        parallel_chunks(3, [&](unsigned c) { decode_plane((int)c); });
     } else {
         for (int c = 0; c < 3; ++c)
             decode_plane(c);

@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 #include "../host_common.h"
@@ -39,13 +40,19 @@ public:
         std::thread th[kThreads];
         for (int t = 0; t < kThreads; ++t) {
             const size_t r0 = rows * t / kThreads, r1 = rows * (t + 1) / kThreads;
-            th[t] = std::thread([=, &err] {
+            auto part = [=, &err] {
                 err[t] = worker(t, device, static_cast<uint8_t *>(dev) + r0 * width, host + r0 * hpitch, hpitch, width,
                                 r1 - r0, to_device);
-            });
+            };
+            try {
+                th[t] = std::thread(part);
+            } catch (const std::system_error &) { // no thread to be had: this part runs here
+                part();
+            }
         }
         for (auto &x : th)
-            x.join();
+            if (x.joinable())
+                x.join();
         for (int t = 0; t < kThreads; ++t)
             if (err[t] != hipSuccess)
                 return jpegamd_fail("staged copy: %s", hipGetErrorString(err[t]));
