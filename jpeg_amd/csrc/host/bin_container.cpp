@@ -566,7 +566,7 @@ int jpegamd_bin_assemble(const JpegamdPlaneCode (&pl)[3], int y_rows, int y_cols
 
 extern "C" {
 
-int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, size_t n_cb,
+static int bin_encode_impl(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, size_t n_cb,
                        const int32_t *sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
                        uint8_t *out, size_t cap, size_t *out_len)
 {
@@ -578,7 +578,7 @@ int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, 
     return jpegamd_bin_assemble(pl, y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
 }
 
-int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
+static int bin_decode_impl(const uint8_t *bin, size_t len, int32_t dims[6],
                        int32_t *sym_y, size_t cap_y, size_t *n_y,
                        int32_t *sym_cb, size_t cap_cb, size_t *n_cb,
                        int32_t *sym_cr, size_t cap_cr, size_t *n_cr)
@@ -669,6 +669,21 @@ int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
         if (status[c] == kTooSmall)
             return fail("bin_decode: symbol buffer too small (the counts needed are in *n_y, *n_cb, *n_cr)");
     return 0;
+}
+
+int jpegamd_bin_encode(const int32_t *sym_y, size_t n_y, const int32_t *sym_cb, size_t n_cb,
+                       const int32_t *sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
+                       uint8_t *out, size_t cap, size_t *out_len)
+{
+    return jpegamd_guarded("bin_encode", [&] { return bin_encode_impl(sym_y, n_y, sym_cb, n_cb, sym_cr, n_cr, y_rows, y_cols, c_rows, c_cols, out, cap, out_len); });
+}
+
+int jpegamd_bin_decode(const uint8_t *bin, size_t len, int32_t dims[6],
+                       int32_t *sym_y, size_t cap_y, size_t *n_y,
+                       int32_t *sym_cb, size_t cap_cb, size_t *n_cb,
+                       int32_t *sym_cr, size_t cap_cr, size_t *n_cr)
+{
+    return jpegamd_guarded("bin_decode", [&] { return bin_decode_impl(bin, len, dims, sym_y, cap_y, n_y, sym_cb, cap_cb, n_cb, sym_cr, cap_cr, n_cr); });
 }
 
 } // extern "C"

@@ -118,7 +118,7 @@ int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]
     return 0;
 }
 
-int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_sym_cb, size_t n_cb,
+static int bin_encode_dev_impl(const int32_t *d_sym_y, size_t n_y, const int32_t *d_sym_cb, size_t n_cb,
                            const int32_t *d_sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
                            uint8_t *out, size_t cap, size_t *out_len)
 {
@@ -144,7 +144,7 @@ int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_
     return jpegamd_bin_assemble(code, y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
 }
 
-int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
+static int compress_image_impl(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
                            const int32_t q_chroma[64], uint8_t **bin, size_t *bin_len)
 {
     if (!bgr || !bin || !bin_len)
@@ -179,7 +179,7 @@ int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride
     return 0;
 }
 
-int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_luma[64], const int32_t q_chroma[64],
+static int decompress_image_impl(const uint8_t *bin, size_t len, const int32_t q_luma[64], const int32_t q_chroma[64],
                              uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows, int *cols)
 {
     if (!bin || !rows || !cols)
@@ -246,6 +246,25 @@ int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_lum
         return 1;
     JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the decode kernel ran on the null stream, the copier uses its own
     return jpegamd_staged_copy(d_out.p, bgr, stride, (size_t)c * 3, r, false);
+}
+
+int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_sym_cb, size_t n_cb,
+                           const int32_t *d_sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
+                           uint8_t *out, size_t cap, size_t *out_len)
+{
+    return jpegamd_guarded("bin_encode_dev", [&] { return bin_encode_dev_impl(d_sym_y, n_y, d_sym_cb, n_cb, d_sym_cr, n_cr, y_rows, y_cols, c_rows, c_cols, out, cap, out_len); });
+}
+
+int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
+                           const int32_t q_chroma[64], uint8_t **bin, size_t *bin_len)
+{
+    return jpegamd_guarded("compress_image", [&] { return compress_image_impl(bgr, rows, cols, stride, q_luma, q_chroma, bin, bin_len); });
+}
+
+int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_luma[64], const int32_t q_chroma[64],
+                             uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows, int *cols)
+{
+    return jpegamd_guarded("decompress_image", [&] { return decompress_image_impl(bin, len, q_luma, q_chroma, bgr, cap_bytes, stride, rows, cols); });
 }
 
 } // extern "C"

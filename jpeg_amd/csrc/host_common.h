@@ -17,6 +17,25 @@ __attribute__((visibility("hidden"))) int jpegamd_staged_copy(void *dev, uint8_t
 __attribute__((visibility("hidden"))) int jpegamd_staged_copy_linear(void *dev, void *host, size_t bytes,
                                                                      bool to_device);
 
+// C++ exceptions must not leave through the C ABI: run `body` and turn any of them into a
+// status with a message (host containers can run out of memory on very large inputs)
+#ifdef __cplusplus
+#include <exception>
+#include <new>
+template <class Body> int jpegamd_guarded(const char *what, Body body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return jpegamd_fail("%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return jpegamd_fail("%s: %s", what, e.what());
+    } catch (...) {
+        return jpegamd_fail("%s: unknown C++ exception", what);
+    }
+}
+#endif
+
 #define JPEGAMD_HIPCHK(expr)                                                                          \
     do {                                                                                              \
         hipError_t e_ = (expr);                                                                       \
