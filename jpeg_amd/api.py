@@ -109,6 +109,28 @@ def decode_image(coef_y, coef_cb, coef_cr, rows, cols, q_luma, q_chroma, out=Non
     return out
 
 
+def encode_images(batch, q_luma, q_chroma, stream=None):
+    """batch: cuda uint8 [n, rows, cols, 3], contiguous -> (coef_y, coef_cb, coef_cr) cuda int16
+    [n, blocks, 64].  MCU rows are independent and an image is a whole number of them, so a
+    batch of equally sized images IS one image of n * rows rows: ONE launch for all of them (a
+    1024^2 image alone fills 128 of the chip's 3072 wave slots)."""
+    n, rows, cols = int(batch.shape[0]), int(batch.shape[1]), int(batch.shape[2])
+    if not batch.is_contiguous():
+        raise ValueError("encode_images: the batch must be contiguous")
+    cy, cb, cr = encode_image(batch.view(n * rows, cols, 3), q_luma, q_chroma, stream=stream)
+    return cy.view(n, -1, 64), cb.view(n, -1, 64), cr.view(n, -1, 64)
+
+
+def decode_images(coef_y, coef_cb, coef_cr, rows, cols, q_luma, q_chroma, stream=None):
+    """inverse of encode_images: coefficient planes [n, blocks, 64] -> cuda uint8 [n, rows, cols, 3]"""
+    n = int(coef_y.shape[0])
+    if not (coef_y.is_contiguous() and coef_cb.is_contiguous() and coef_cr.is_contiguous()):
+        raise ValueError("decode_images: the coefficient planes must be contiguous")
+    out = decode_image(coef_y.view(-1, 64), coef_cb.view(-1, 64), coef_cr.view(-1, 64), n * int(rows), int(cols),
+                       q_luma, q_chroma, stream=stream)
+    return out.view(n, int(rows), int(cols), 3)
+
+
 def encode_plane(plane, q, stream=None):
     """plane: cuda uint8 [rows, cols] (any size) -> cuda int16 [blocks, 64] zigzag."""
     import torch

@@ -132,6 +132,24 @@ def test_config3_full_size_gray(gpu, orc):
     assert np.array_equal(back, rec.cpu().numpy())
 
 
+def test_batch_in_one_launch_is_the_images_one_by_one(gpu):
+    """config 4 for small images: a contiguous batch of equally sized images is one image of
+    n * rows rows (MCU rows are independent), so it goes through ONE encode and ONE decode
+    launch; coefficients and pixels equal the per-image calls bit for bit."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    rows, cols, n = 48, 528, 5
+    qy, qc = jpeg_amd.quality_tables(75)
+    batch = torch.stack([synth_image(rows, cols, 70 + i, "noise" if i == 2 else "photo", device=gpu) for i in range(n)])
+    cy, cb, cr = jpeg_amd.encode_images(batch, qy, qc)
+    assert cy.shape == (n, rows * cols // 64, 64) and cb.shape == (n, rows * cols // 256, 64)
+    rec = jpeg_amd.decode_images(cy, cb, cr, rows, cols, qy, qc)
+    for i in range(n):
+        one = jpeg_amd.encode_image(batch[i], qy, qc)
+        assert torch.equal(one[0], cy[i]) and torch.equal(one[1], cb[i]) and torch.equal(one[2], cr[i])
+        assert torch.equal(jpeg_amd.decode_image(*one, rows, cols, qy, qc), rec[i])
+
+
 def test_config4_full_size_batch(gpu, orc):
     """config 4 at its real image size (3840 x 2160: 7.5 wave tiles per row, so every MCU row
     ends in a half-filled tile): images of a batch processed back to back on two streams equal
