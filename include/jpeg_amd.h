@@ -71,7 +71,11 @@ int jpegamd_decode_plane_dev(const int16_t *d_coef_zz, int rows, int cols, const
 /* ---- fused colour image ----------------------------------------------------- */
 /* RGB2YCbCr (encode_decode.cpp:39-75) + chromaSubsampling (117-152) + the three
  * encodeChannelGPU transforms (720-743) of mainEncode (1327-1329) in ONE launch.
- * d_coef_y: (rows/8)*(cols/8)*64 int16; d_coef_cb/cr: (rows/16)*(cols/16)*64. */
+ * d_coef_y: (rows/8)*(cols/8)*64 int16; d_coef_cb/cr: (rows/16)*(cols/16)*64.
+ * A batch: n equally sized images stored back to back are one image of n*rows rows
+ * (MCU rows are independent); their coefficient planes come out back to back.  The
+ * same holds for jpegamd_decode_image_dev.  One launch fills the GPU where a small
+ * image alone cannot. */
 int jpegamd_encode_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride,
                              const int32_t q_luma[64], const int32_t q_chroma[64],
                              int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr,
