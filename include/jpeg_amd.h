@@ -32,7 +32,9 @@ extern "C" {
 #endif
 
 /* Selects `device` for the calling thread and checks that it is a gfx950.
- * Fails loudly if there is no usable GPU: there is no CPU fallback. */
+ * Fails loudly if there is no usable GPU: there is no CPU fallback.  Also creates the
+ * pinned staging buffers (32 MiB) and copy streams the host-pointer entry points use,
+ * which their first call would otherwise create. */
 int jpegamd_init(int device);
 const char *jpegamd_last_error(void);
 /* Library/ABI version, bumped when a signature changes. */

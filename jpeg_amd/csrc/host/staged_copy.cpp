@@ -59,6 +59,15 @@ public:
         return 0;
     }
 
+    // creates the staging buffers, streams and events for the current device ahead of the first copy
+    int warm()
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        int device = 0;
+        JPEGAMD_HIPCHK(hipGetDevice(&device));
+        return prepare(device);
+    }
+
 private:
     static constexpr int kThreads = 4;
     static constexpr size_t kChunk = 4u << 20;
@@ -143,6 +152,8 @@ int jpegamd_staged_copy(void *dev, uint8_t *host, size_t hpitch, size_t width, s
 {
     return g_copier.copy(dev, host, hpitch, width, rows, to_device);
 }
+
+int jpegamd_staged_copy_warm() { return g_copier.warm(); }
 
 // one contiguous range: whole 4 KiB rows through the staged copier, the tail directly
 int jpegamd_staged_copy_linear(void *dev, void *host, size_t bytes, bool to_device)
