@@ -69,8 +69,14 @@ public:
     }
 
 private:
-    static constexpr int kThreads = 4;
-    static constexpr size_t kChunk = 4u << 20;
+#ifndef JPEGAMD_COPY_THREADS
+#define JPEGAMD_COPY_THREADS 4
+#endif
+#ifndef JPEGAMD_COPY_CHUNK_MIB
+#define JPEGAMD_COPY_CHUNK_MIB 4
+#endif
+    static constexpr int kThreads = JPEGAMD_COPY_THREADS;
+    static constexpr size_t kChunk = (size_t)JPEGAMD_COPY_CHUNK_MIB << 20;
     std::mutex mu_;
     int device_ = -1;
     void *pin_[kThreads][2] = {};
