@@ -69,6 +69,12 @@ def load():
             raise JpegAmdError(
                 f"{LIB_PATH} is missing: build it with `make -C jpeg_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
+        # torch ships a HIP runtime of its own.  The library must bind to the SAME runtime as
+        # the tensors whose device pointers it is handed, and a process that loads the system's
+        # runtime first and torch's second ends up with two: the second one then finds "no
+        # ROCm-capable device".  Importing torch first makes the loader resolve
+        # libamdhip64.so.7 to the copy that is already there.
+        import torch  # noqa: F401
         lib = _c.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -1,7 +1,7 @@
 // jpegamd_main: the GPU branch of the reference's command-line harness
 // (main.cpp:22-337) on top of libjpeg_amd.so.
 //
-//   echo image.ppm | jpegamd_main [-q N] [-o DIR]
+//   echo image.png | jpegamd_main [-q N] [-o DIR]
 //
 // Same protocol as main.cpp: `-q N` (1..100, default 50, :24-47), the image
 // name is read from stdin after the "Enter the image name: " prompt (:84-85),
@@ -10,9 +10,10 @@
 // :150, :171, :191-194, :244, :264, :328-330).
 //
 // Differences, on purpose:
-//  * no OpenCV in this image: the input is a binary PPM (P6, maxval 255) and the
-//    reconstruction is written as DIR/decompress_image_gpu_<q>.ppm (main.cpp
-//    reads anything imread does and writes PNG, :300);
+//  * no OpenCV in this image: the input is a PNG (png_io.h: zlib only, what imread's
+//    8-bit colour mode makes of the non-interlaced files the reference ships) or a
+//    binary PPM (P6, maxval 255); the reconstruction is written in the input's format
+//    as DIR/decompress_image_gpu_<q>.png (main.cpp:300) or .ppm;
 //  * ensureMultipleOf16 (encode_decode.cpp:29-37) resizes with cv::INTER_AREA;
 //    here an image whose sides are not multiples of 16 is rejected;
 //  * only the GPU leg runs, so there are no CPU/OMP lines and no speed-up lines;
@@ -32,6 +33,7 @@
 extern "C" {
 #include "../../../include/jpeg_amd.h"
 }
+#include "png_io.h"
 
 namespace {
 
@@ -87,6 +89,26 @@ Image read_ppm(const std::string &path)
         img.bgr[3 * i + 1] = rgb[3 * i + 1];
         img.bgr[3 * i + 2] = rgb[3 * i + 0];
     }
+    return img;
+}
+
+// PNG by its signature, otherwise PPM; *png tells which
+Image read_image(const std::string &path, bool *png)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in)
+        throw std::runtime_error("Could not open or find the image"); // readImage, encode_decode.cpp:23
+    uint8_t sig[8] = {0};
+    in.read((char *)sig, 8);
+    *png = in.gcount() == 8 && pngio::is_png(std::vector<uint8_t>(sig, sig + 8));
+    if (!*png)
+        return read_ppm(path);
+    in.seekg(0, std::ios::end);
+    std::vector<uint8_t> file((size_t)in.tellg());
+    in.seekg(0);
+    in.read((char *)file.data(), (std::streamsize)file.size());
+    Image img;
+    pngio::decode(file, img.rows, img.cols, img.bgr);
     return img;
 }
 
@@ -163,7 +185,8 @@ int main(int argc, char *argv[])
         std::string image_name;
         cout << "Enter the image name: ";
         std::cin >> image_name;
-        const Image image = read_ppm(image_name);
+        bool png = false;
+        const Image image = read_image(image_name, &png);
         if (image.rows % 16 || image.cols % 16)
             throw std::runtime_error("image sides must be multiples of 16 (the reference resizes with OpenCV; "
                                      "this harness does not)");
@@ -234,7 +257,11 @@ int main(int argc, char *argv[])
         cout << "Decoding time (GPU): " << decode_ms << " ms" << endl;
         cout << "======================================\n\n";
 
-        write_ppm(out_dir + "/decompress_image_gpu_" + std::to_string(quality) + ".ppm", rec);
+        const std::string rec_name = out_dir + "/decompress_image_gpu_" + std::to_string(quality);
+        if (png)
+            pngio::write(rec_name + ".png", rec.rows, rec.cols, rec.bgr.data());
+        else
+            write_ppm(rec_name + ".ppm", rec);
 
         if (rec.rows != image.rows || rec.cols != image.cols)
             throw std::runtime_error("Images must have the same size and type for MSE calculation.");

@@ -97,6 +97,26 @@ def test_harness_lena_quality_50(gpu, orc, lena_bgr, tmp_path):
 
 
 @pytest.mark.gpu
+def test_harness_reads_the_reference_png_and_writes_png(gpu, lena_bgr, tmp_path):
+    """main.cpp reads img/lena_color_1024.png with cv::imread and writes the reconstruction
+    with cv::imwrite(".png") (:86, :300): the same file in, the committed golden .bin out, and
+    a PNG of the reconstruction that PIL reads back as the library's own pixels."""
+    import shutil
+    from PIL import Image
+    import jpeg_amd
+    shutil.copy(os.path.join(GOLD, "lena_color_1024.png"), tmp_path / "lena_color_1024.png")
+    os.mkdir(tmp_path / "output")
+    r = _run(["-q", "50"], "lena_color_1024.png\n", tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "Image Dimensions: 1024 x 1024" in r.stdout
+    data = (tmp_path / "output" / "compressed_image_gpu_50.bin").read_bytes()
+    assert hashlib.sha256(data).hexdigest() == "7870d3fec500635c7ef9dc5a98f985f31dbb2c91b0beb8d0c6ba9f9dbf82b2bf"
+    rec = np.array(Image.open(tmp_path / "output" / "decompress_image_gpu_50.png").convert("RGB"))[:, :, ::-1]
+    assert np.array_equal(rec, jpeg_amd.decompress_image(data, *jpeg_amd.quality_tables(50)))
+    assert abs(float(re.search(r"PSNR: ([\d.]+) dB", r.stdout).group(1)) - 35.2317) < 0.01
+
+
+@pytest.mark.gpu
 def test_harness_other_quality_and_output_dir(gpu, tmp_path):
     import jpeg_amd
     from jpeg_amd.synth import synth_image
