@@ -10,10 +10,10 @@
 // :150, :171, :191-194, :244, :264, :328-330).
 //
 // Differences, on purpose:
-//  * no OpenCV in this image: the input is a PNG (png_io.h: zlib only, what imread's
-//    8-bit colour mode makes of the non-interlaced files the reference ships) or a
-//    binary PPM (P6, maxval 255); the reconstruction is written in the input's format
-//    as DIR/decompress_image_gpu_<q>.png (main.cpp:300) or .ppm;
+//  * no OpenCV in this image: the input is a PNG or an uncompressed 8-bit TIFF (png_io.h:
+//    zlib only, what imread's 8-bit colour mode makes of the kinds of file the reference
+//    ships) or a binary PPM (P6, maxval 255); the reconstruction is written as
+//    DIR/decompress_image_gpu_<q>.png (main.cpp:300), for a PPM input as .ppm;
 //  * ensureMultipleOf16 (encode_decode.cpp:29-37) resizes with cv::INTER_AREA;
 //    here an image whose sides are not multiples of 16 is rejected;
 //  * only the GPU leg runs, so there are no CPU/OMP lines and no speed-up lines;
@@ -92,7 +92,7 @@ Image read_ppm(const std::string &path)
     return img;
 }
 
-// PNG by its signature, otherwise PPM; *png tells which
+// PNG or TIFF by their signatures, otherwise PPM; *png: write the reconstruction as PNG
 Image read_image(const std::string &path, bool *png)
 {
     std::ifstream in(path, std::ios::binary);
@@ -100,15 +100,21 @@ Image read_image(const std::string &path, bool *png)
         throw std::runtime_error("Could not open or find the image"); // readImage, encode_decode.cpp:23
     uint8_t sig[8] = {0};
     in.read((char *)sig, 8);
-    *png = in.gcount() == 8 && pngio::is_png(std::vector<uint8_t>(sig, sig + 8));
+    const std::vector<uint8_t> head(sig, sig + (in.gcount() == 8 ? 8 : 0));
+    const bool tiff = tiffio::is_tiff(head);
+    *png = pngio::is_png(head) || tiff; // either way the reconstruction is written as PNG, like main.cpp:300
     if (!*png)
         return read_ppm(path);
+    in.clear();
     in.seekg(0, std::ios::end);
     std::vector<uint8_t> file((size_t)in.tellg());
     in.seekg(0);
     in.read((char *)file.data(), (std::streamsize)file.size());
     Image img;
-    pngio::decode(file, img.rows, img.cols, img.bgr);
+    if (tiff)
+        tiffio::decode(file, img.rows, img.cols, img.bgr);
+    else
+        pngio::decode(file, img.rows, img.cols, img.bgr);
     return img;
 }
 

@@ -1,4 +1,5 @@
-// png_io.h -- PNG in and out for the command-line harness (jpegamd_main), on zlib alone.
+// png_io.h -- PNG in and out, and baseline TIFF in, for the command-line harness (jpegamd_main),
+// on zlib alone.
 // The reference reads its inputs with cv::imread(path, IMREAD_COLOR) and writes the
 // reconstruction with cv::imwrite(".png") (main.cpp:86, :300); its own test images are PNG
 // files.  OpenCV is not in this image, zlib is.  What imread's 8-bit colour mode makes of a PNG
@@ -186,4 +187,98 @@ inline void write(const std::string &path, int rows, int cols, const uint8_t *bg
 }
 
 } // namespace pngio
+
+// Baseline TIFF, as far as the reference's own img/*.tif need it: uncompressed strips of 8-bit
+// grey (either photometric sense) or RGB / RGBA samples, chunky layout, either byte order.
+namespace tiffio {
+
+inline bool is_tiff(const std::vector<uint8_t> &f)
+{
+    return f.size() >= 8 && ((f[0] == 'I' && f[1] == 'I' && f[2] == 42 && f[3] == 0) ||
+                             (f[0] == 'M' && f[1] == 'M' && f[2] == 0 && f[3] == 42));
+}
+
+inline void decode(const std::vector<uint8_t> &f, int &rows, int &cols, std::vector<uint8_t> &bgr)
+{
+    if (!is_tiff(f))
+        throw std::runtime_error("not a TIFF file");
+    const bool le = f[0] == 'I';
+    auto u16 = [&](size_t o) -> uint32_t {
+        if (o + 2 > f.size())
+            throw std::runtime_error("TIFF structure runs past the end of the file");
+        return le ? (uint32_t)f[o] | ((uint32_t)f[o + 1] << 8) : ((uint32_t)f[o] << 8) | f[o + 1];
+    };
+    auto u32 = [&](size_t o) -> uint32_t {
+        if (o + 4 > f.size())
+            throw std::runtime_error("TIFF structure runs past the end of the file");
+        return le ? u16(o) | (u16(o + 2) << 16) : (u16(o) << 16) | u16(o + 2);
+    };
+    const size_t ifd = u32(4);
+    const uint32_t n = u16(ifd);
+    uint32_t w = 0, h = 0, bits = 1, compression = 1, photometric = 1, spp = 1, rows_per_strip = 0xFFFFFFFFu, planar = 1;
+    std::vector<uint32_t> offsets, counts;
+    auto values = [&](size_t entry, std::vector<uint32_t> &out) { // SHORT or LONG arrays, inline or at an offset
+        const uint32_t type = u16(entry + 2), count = u32(entry + 4);
+        const size_t size = type == 3 ? 2 : type == 4 ? 4 : 0;
+        if (!size || count > (1u << 24))
+            throw std::runtime_error("TIFF field of an unsupported type");
+        size_t at = size * count <= 4 ? entry + 8 : u32(entry + 8);
+        out.clear();
+        for (uint32_t i = 0; i < count; ++i, at += size)
+            out.push_back(size == 2 ? u16(at) : u32(at));
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        const size_t e = ifd + 2 + 12 * (size_t)i;
+        std::vector<uint32_t> v;
+        switch (u16(e)) {
+        case 256: values(e, v); w = v.at(0); break;
+        case 257: values(e, v); h = v.at(0); break;
+        case 258:
+            values(e, v);
+            bits = v.at(0);
+            for (uint32_t b : v)
+                if (b != bits)
+                    throw std::runtime_error("TIFF with different bit depths per sample is not supported");
+            break;
+        case 259: values(e, v); compression = v.at(0); break;
+        case 262: values(e, v); photometric = v.at(0); break;
+        case 273: values(e, offsets); break;
+        case 277: values(e, v); spp = v.at(0); break;
+        case 278: values(e, v); rows_per_strip = v.at(0); break;
+        case 279: values(e, counts); break;
+        case 284: values(e, v); planar = v.at(0); break;
+        default: break;
+        }
+    }
+    if (w == 0 || h == 0 || w > 65535 || h > 65535 || offsets.empty())
+        throw std::runtime_error("TIFF without image dimensions or strips");
+    if (compression != 1)
+        throw std::runtime_error("compressed TIFF files are not supported (only uncompressed strips)");
+    if (bits != 8 || planar != 1 || !((photometric <= 1 && spp >= 1) || (photometric == 2 && spp >= 3)))
+        throw std::runtime_error("TIFF layout not supported (8-bit grey or RGB, chunky, is)");
+    rows = (int)h, cols = (int)w;
+    bgr.resize((size_t)w * h * 3);
+    const size_t line = (size_t)w * spp;
+    rows_per_strip = rows_per_strip < h ? rows_per_strip : h;
+    for (uint32_t y = 0; y < h; ++y) {
+        const size_t strip = y / rows_per_strip;
+        if (strip >= offsets.size())
+            throw std::runtime_error("TIFF strip table is too short");
+        const size_t at = (size_t)offsets[strip] + (size_t)(y % rows_per_strip) * line;
+        if (at + line > f.size())
+            throw std::runtime_error("TIFF strip runs past the end of the file");
+        const uint8_t *src = &f[at];
+        uint8_t *out = &bgr[(size_t)y * w * 3];
+        for (uint32_t x = 0; x < w; ++x) {
+            if (photometric == 2) {
+                out[3 * x] = src[x * spp + 2], out[3 * x + 1] = src[x * spp + 1], out[3 * x + 2] = src[x * spp];
+            } else {
+                const uint8_t v = photometric == 0 ? (uint8_t)(255 - src[x * spp]) : src[x * spp];
+                out[3 * x] = out[3 * x + 1] = out[3 * x + 2] = v;
+            }
+        }
+    }
+}
+
+} // namespace tiffio
 #endif

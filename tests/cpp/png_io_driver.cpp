@@ -18,7 +18,10 @@ int main(int argc, char **argv)
         if (std::string(argv[1]) == "decode") {
             int rows, cols;
             std::vector<uint8_t> bgr;
-            pngio::decode(file, rows, cols, bgr);
+            if (tiffio::is_tiff(file))
+                tiffio::decode(file, rows, cols, bgr);
+            else
+                pngio::decode(file, rows, cols, bgr);
             std::ofstream out(argv[3], std::ios::binary);
             const int32_t dims[2] = {rows, cols};
             out.write((const char *)dims, 8);

@@ -114,6 +114,13 @@ def test_harness_reads_the_reference_png_and_writes_png(gpu, lena_bgr, tmp_path)
     rec = np.array(Image.open(tmp_path / "output" / "decompress_image_gpu_50.png").convert("RGB"))[:, :, ::-1]
     assert np.array_equal(rec, jpeg_amd.decompress_image(data, *jpeg_amd.quality_tables(50)))
     assert abs(float(re.search(r"PSNR: ([\d.]+) dB", r.stdout).group(1)) - 35.2317) < 0.01
+    # the same picture as an uncompressed TIFF (the format of the reference's other samples)
+    Image.fromarray(np.ascontiguousarray(lena_bgr[:, :, ::-1])).save(tmp_path / "lena.tif", compression=None)
+    os.mkdir(tmp_path / "tif")
+    r = _run(["-q", "50", "-o", "tif"], "lena.tif\n", tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "tif" / "compressed_image_gpu_50.bin").read_bytes() == data
+    assert (tmp_path / "tif" / "decompress_image_gpu_50.png").exists()
 
 
 @pytest.mark.gpu

@@ -46,6 +46,36 @@ def test_colour_types_and_filters(tmp_path, mode):
     assert np.array_equal(got[:, :, ::-1], want)
 
 
+@pytest.mark.parametrize("mode,kw", [("RGB", {}), ("L", {}), ("RGBA", {}), ("RGB", {"big": True})])
+def test_uncompressed_tiff(tmp_path, mode, kw):
+    """the reference's img/*.tif are uncompressed 8-bit grey or RGB files"""
+    rng = np.random.default_rng(8)
+    rgb = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    im = Image.fromarray(rgb, "RGB").convert(mode)
+    path = tmp_path / "a.tif"
+    im.save(path, compression=None)
+    if kw.get("big"):  # the same file in the other byte order, written by hand
+        w, h = im.size
+        data = np.array(im).tobytes()
+        tags = [(256, 3, 1, w), (257, 3, 1, h), (258, 3, 1, 8), (259, 3, 1, 1), (262, 3, 1, 2), (273, 4, 1, 8),
+                (277, 3, 1, 3), (278, 3, 1, h), (279, 4, 1, len(data))]
+        ifd_at = 8 + len(data) + (len(data) & 1)
+        ifd = len(tags).to_bytes(2, "big")
+        for tag, typ, cnt, val in tags:
+            ifd += tag.to_bytes(2, "big") + typ.to_bytes(2, "big") + cnt.to_bytes(4, "big")
+            ifd += val.to_bytes(2, "big") + b"\0\0" if typ == 3 else val.to_bytes(4, "big")
+        path.write_bytes(b"MM\0*" + ifd_at.to_bytes(4, "big") + data + b"\0" * (len(data) & 1) + ifd + b"\0\0\0\0")
+        # (bits per sample 8 given once for three samples: readers take it for all of them)
+    got = _decode(path, tmp_path)
+    assert np.array_equal(got[:, :, ::-1], np.array(Image.open(path).convert("RGB")))
+
+
+def test_compressed_tiff_is_refused(tmp_path):
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(tmp_path / "z.tif", compression="tiff_lzw")
+    with pytest.raises(RuntimeError, match="compressed TIFF"):
+        _decode(tmp_path / "z.tif", tmp_path)
+
+
 def test_writer_is_read_back_by_pil(tmp_path):
     rng = np.random.default_rng(4)
     bgr = rng.integers(0, 256, (48, 80, 3), dtype=np.uint8)
