@@ -4,7 +4,9 @@
 // host entropy coder -> .bin bytes, and the inverse.  Device memory is allocated
 // and freed per call, like the reference's kernel.cu:97-104 / 160-164.
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -41,6 +43,38 @@ struct HostSymbols {
         n = p ? count : 0;
         return p != nullptr;
     }
+};
+
+// JPEGAMD_TRACE=1: the host-pointer calls report where their time went, on stderr
+class StageTrace {
+  public:
+    explicit StageTrace(const char *what) : on_(std::getenv("JPEGAMD_TRACE") != nullptr), what_(what), last_(now()) {}
+    void mark(const char *stage) // time since the previous mark (device work is synchronised first)
+    {
+        if (!on_)
+            return;
+        (void)hipDeviceSynchronize();
+        const double t = now();
+        n_ += std::snprintf(line_ + n_, sizeof line_ - (size_t)n_, " %s %.2f", stage, t - last_);
+        n_ = n_ < (int)sizeof line_ ? n_ : (int)sizeof line_ - 1;
+        last_ = now();
+    }
+    ~StageTrace()
+    {
+        if (on_)
+            std::fprintf(stderr, "jpeg_amd %s [ms]:%s\n", what_, line_);
+    }
+
+  private:
+    static double now()
+    {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    bool on_;
+    const char *what_;
+    double last_;
+    char line_[256] = "";
+    int n_ = 0;
 };
 
 // JPEGAMD_ENTROPY=host keeps both passes of the entropy stage on the host (the first
@@ -153,18 +187,23 @@ static int compress_image_impl(const uint8_t *bgr, int rows, int cols, size_t st
         return jpegamd_fail("compress_image: rows=%d cols=%d must be positive multiples of 16 and stride >= 3*cols "
                             "(the reference resizes first, encode_decode.cpp:29-37)", rows, cols);
     const size_t nby = (size_t)(rows / 8) * (cols / 8), nbc = (size_t)(rows / 16) * (cols / 16);
+    StageTrace trace("compress_image");
     DevMem d_bgr, d_y, d_cb, d_cr;
     if (d_bgr.alloc((size_t)rows * cols * 3) || d_y.alloc(nby * 128) || d_cb.alloc(nbc * 128) || d_cr.alloc(nbc * 128))
         return jpegamd_fail("compress_image: out of device memory");
+    trace.mark("alloc");
     if (jpegamd_staged_copy(d_bgr.p, const_cast<uint8_t *>(bgr), stride, (size_t)cols * 3, rows, true))
         return 1;
+    trace.mark("upload");
     if (jpegamd_encode_image_dev(d_bgr.as<uint8_t>(), rows, cols, (size_t)cols * 3, q_luma, q_chroma,
                                  d_y.as<int16_t>(), d_cb.as<int16_t>(), d_cr.as<int16_t>(), nullptr))
         return 1;
+    trace.mark("transform");
     JpegamdPlaneCode code[3];
     if (plane_code(d_y.as<int16_t>(), nby, code[0]) || plane_code(d_cb.as<int16_t>(), nbc, code[1]) ||
         plane_code(d_cr.as<int16_t>(), nbc, code[2]))
         return 1;
+    trace.mark("run-length+entropy");
     size_t need = 0;
     (void)jpegamd_bin_assemble(code, rows, cols, rows / 2, cols / 2, nullptr, 0, &need); // sizing call
     uint8_t *buf = static_cast<uint8_t *>(std::malloc(need ? need : 1));
@@ -176,6 +215,7 @@ static int compress_image_impl(const uint8_t *bgr, int rows, int cols, size_t st
     }
     *bin = buf;
     *bin_len = need;
+    trace.mark("assemble");
     return 0;
 }
 
@@ -219,9 +259,11 @@ static int decompress_image_impl(const uint8_t *bin, size_t len, const int32_t q
             return jpegamd_fail("decompress_image: out of host memory");
         sym[k].n = cap;
     }
+    StageTrace trace("decompress_image");
     if (jpegamd_bin_decode(bin, len, dims, sym[0].p, sym[0].n, &n[0], sym[1].p, sym[1].n, &n[1], sym[2].p, sym[2].n,
                            &n[2]))
         return 1; // includes "more symbols than the plane sizes in the header allow"
+    trace.mark("entropy-decode");
     for (int k = 0; k < 3; ++k)
         sym[k].n = n[k];
     DevMem d_coef[3], d_out;
@@ -239,13 +281,17 @@ static int decompress_image_impl(const uint8_t *bin, size_t len, const int32_t q
             return 1;
         JPEGAMD_HIPCHK(hipDeviceSynchronize()); // d_pairs and work are freed at the end of this iteration
     }
+    trace.mark("upload+run-length");
     if (d_out.alloc((size_t)r * c * 3))
         return jpegamd_fail("decompress_image: out of device memory");
     if (jpegamd_decode_image_dev(d_coef[0].as<int16_t>(), d_coef[1].as<int16_t>(), d_coef[2].as<int16_t>(), r, c,
                                  q_luma, q_chroma, d_out.as<uint8_t>(), (size_t)c * 3, nullptr))
         return 1;
     JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the decode kernel ran on the null stream, the copier uses its own
-    return jpegamd_staged_copy(d_out.p, bgr, stride, (size_t)c * 3, r, false);
+    trace.mark("transform");
+    const int rc = jpegamd_staged_copy(d_out.p, bgr, stride, (size_t)c * 3, r, false);
+    trace.mark("download");
+    return rc;
 }
 
 int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_sym_cb, size_t n_cb,
