@@ -266,24 +266,26 @@ static int decompress_image_impl(const uint8_t *bin, size_t len, const int32_t q
     trace.mark("entropy-decode");
     for (int k = 0; k < 3; ++k)
         sym[k].n = n[k];
-    DevMem d_coef[3], d_out;
+    // every buffer of the call up front: the planes then go through without a wait between them
+    DevMem d_coef[3], d_pairs[3], work[3], d_out;
+    size_t use[3], wbytes[3];
     for (int k = 0; k < 3; ++k) {
-        DevMem d_pairs, work;
         const size_t np = sym[k].size() / 2; // an odd trailing symbol has no run: dropped
-        const size_t use = np < nb[k] * 64 + 8 ? np : nb[k] * 64 + 8; // pairs beyond that cannot reach the plane
-        const size_t wbytes = jpegamd_rle_workspace_bytes(nb[k]);
-        if (d_coef[k].alloc(nb[k] * 128) || d_pairs.alloc(use * 8) || work.alloc(wbytes))
+        use[k] = np < nb[k] * 64 + 8 ? np : nb[k] * 64 + 8; // pairs beyond that cannot reach the plane
+        wbytes[k] = jpegamd_rle_workspace_bytes(nb[k]);
+        if (d_coef[k].alloc(nb[k] * 128) || d_pairs[k].alloc(use[k] * 8) || work[k].alloc(wbytes[k]))
             return jpegamd_fail("decompress_image: out of device memory");
-        if (use && jpegamd_staged_copy_linear(d_pairs.p, sym[k].p, use * 8, true))
-            return 1;
-        if (jpegamd_rle_decode_plane_dev(d_pairs.as<int32_t>(), use, nb[k], d_coef[k].as<int16_t>(), work.p, wbytes,
-                                         nullptr))
-            return 1;
-        JPEGAMD_HIPCHK(hipDeviceSynchronize()); // d_pairs and work are freed at the end of this iteration
     }
-    trace.mark("upload+run-length");
     if (d_out.alloc((size_t)r * c * 3))
         return jpegamd_fail("decompress_image: out of device memory");
+    for (int k = 0; k < 3; ++k) {
+        if (use[k] && jpegamd_staged_copy_linear(d_pairs[k].p, sym[k].p, use[k] * 8, true)) // returns when the data is there
+            return 1;
+        if (jpegamd_rle_decode_plane_dev(d_pairs[k].as<int32_t>(), use[k], nb[k], d_coef[k].as<int16_t>(), work[k].p,
+                                         wbytes[k], nullptr))
+            return 1;
+    }
+    trace.mark("upload+run-length");
     if (jpegamd_decode_image_dev(d_coef[0].as<int16_t>(), d_coef[1].as<int16_t>(), d_coef[2].as<int16_t>(), r, c,
                                  q_luma, q_chroma, d_out.as<uint8_t>(), (size_t)c * 3, nullptr))
         return 1;
