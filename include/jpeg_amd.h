@@ -160,6 +160,21 @@ int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride
 int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_luma[64], const int32_t q_chroma[64],
                              uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows, int *cols);
 void jpegamd_free(void *p);
+
+/* A context keeps the device buffers of the two calls above from call to call, where the
+ * plain calls allocate and free them each time like the reference's kernel.cu:97-104 and
+ * 160-164 (no counterpart in the reference; SURVEY.md 8b proposes it).  `device` is selected
+ * only for the duration of a call.  One call at a time per context (serialised inside);
+ * buffers grow to the largest image seen and are released by jpegamd_context_destroy. */
+typedef struct jpegamd_context jpegamd_context;
+int jpegamd_context_create(int device, jpegamd_context **ctx);
+void jpegamd_context_destroy(jpegamd_context *ctx);
+int jpegamd_context_compress_image(jpegamd_context *ctx, const uint8_t *bgr, int rows, int cols, size_t stride,
+                                   const int32_t q_luma[64], const int32_t q_chroma[64], uint8_t **bin,
+                                   size_t *bin_len);
+int jpegamd_context_decompress_image(jpegamd_context *ctx, const uint8_t *bin, size_t len, const int32_t q_luma[64],
+                                     const int32_t q_chroma[64], uint8_t *bgr, size_t cap_bytes, size_t stride,
+                                     int *rows, int *cols);
 /* main.cpp:3-20, 51-80: the Annex-K base tables scaled for quality 1..100
  * (row-major 8x8, clamped to 1..255); non-zero for a quality outside that range. */
 int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]);

@@ -49,6 +49,12 @@ SIGNATURES = {
                                _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)],
     "jpegamd_decompress_image": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
                                  _c.c_size_t, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)],
+    "jpegamd_context_create": [_c.c_int, _c.POINTER(_c.c_void_p)],
+    "jpegamd_context_compress_image": [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p,
+                                       _c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)],
+    "jpegamd_context_decompress_image": [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                                         _c.c_void_p, _c.c_size_t, _c.c_size_t, _c.POINTER(_c.c_int),
+                                         _c.POINTER(_c.c_int)],
     "jpegamd_time_image_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                _c.POINTER(_c.c_float), _c.POINTER(_c.c_float)],
@@ -84,6 +90,8 @@ def load():
         lib.jpegamd_rle_workspace_bytes.restype = _c.c_size_t
         lib.jpegamd_free.argtypes = [_c.c_void_p]
         lib.jpegamd_free.restype = None
+        lib.jpegamd_context_destroy.argtypes = [_c.c_void_p]
+        lib.jpegamd_context_destroy.restype = None
         lib.jpegamd_last_error.argtypes = []
         lib.jpegamd_last_error.restype = _c.c_char_p
         _lib = lib

@@ -294,3 +294,54 @@ def decompress_image(data, q_luma, q_chroma):
     _lib.check(lib.jpegamd_decompress_image(buf.ctypes.data, buf.size, pl, pc, out.ctypes.data, out.size,
                                             c.value * 3, ctypes.byref(r), ctypes.byref(c)))
     return out
+
+
+class Context:
+    """jpegamd_context: compress_image / decompress_image with device buffers kept from call
+    to call (use as a context manager, or call close())."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._ctx = ctypes.c_void_p()
+        _lib.check(self._lib.jpegamd_context_create(int(device), ctypes.byref(self._ctx)))
+
+    def close(self):
+        if self._ctx:
+            self._lib.jpegamd_context_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    def compress_image(self, bgr, q_luma, q_chroma):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        ql, pl = _q(q_luma)
+        qc, pc = _q(q_chroma)
+        out, n = ctypes.c_void_p(), ctypes.c_size_t(0)
+        _lib.check(self._lib.jpegamd_context_compress_image(self._ctx, bgr.ctypes.data, bgr.shape[0], bgr.shape[1],
+                                                            bgr.shape[1] * 3, pl, pc, ctypes.byref(out),
+                                                            ctypes.byref(n)))
+        try:
+            return ctypes.string_at(out, n.value)
+        finally:
+            self._lib.jpegamd_free(out)
+
+    def decompress_image(self, data, q_luma, q_chroma, out=None):
+        buf = np.frombuffer(data, np.uint8)
+        ql, pl = _q(q_luma)
+        qc, pc = _q(q_chroma)
+        r, c = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.jpegamd_context_decompress_image(self._ctx, buf.ctypes.data, buf.size, pl, pc, None, 0, 0,
+                                                              ctypes.byref(r), ctypes.byref(c)))
+        if out is None:
+            out = np.empty((r.value, c.value, 3), np.uint8)
+        _lib.check(self._lib.jpegamd_context_decompress_image(self._ctx, buf.ctypes.data, buf.size, pl, pc,
+                                                              out.ctypes.data, out.size, c.value * 3,
+                                                              ctypes.byref(r), ctypes.byref(c)))
+        return out

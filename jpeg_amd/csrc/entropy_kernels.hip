@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "host/dev_alloc.h"
 #include "host/entropy_internal.h"
 #include "host_common.h"
 
@@ -185,16 +186,7 @@ __global__ __launch_bounds__(kThreads) void sym_pack_kernel(const int32_t *__res
         atomicOr(out, __builtin_bswap32((uint32_t)(acc << (32 - have))));
 }
 
-struct DevMem {
-    void *p = nullptr;
-    ~DevMem()
-    {
-        if (p)
-            (void)hipFree(p);
-    }
-    int alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess ? 0 : 1; }
-    template <class T> T *as() { return static_cast<T *>(p); }
-};
+typedef JpegamdDevMem DevMem; // per call, or a slot of the running context call (host/dev_alloc.h)
 
 } // namespace
 

@@ -9,25 +9,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
 #include <vector>
 
 #include "../../../include/jpeg_amd.h"
 #include "../host_common.h"
+#include "dev_alloc.h"
 #include "entropy_internal.h"
 
 namespace {
 
 
-struct DevMem {
-    void *p = nullptr;
-    ~DevMem()
-    {
-        if (p)
-            (void)hipFree(p);
-    }
-    int alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess ? 0 : 1; }
-    template <class T> T *as() { return static_cast<T *>(p); }
-};
+typedef JpegamdDevMem DevMem; // per call, or a slot of the running context call (dev_alloc.h)
 
 // malloc'ed, deliberately uninitialised host array (a std::vector would zero 76 MB first)
 struct HostSymbols {
@@ -94,11 +88,7 @@ int plane_code(const int16_t *d_coef, size_t nb, JpegamdPlaneCode &code)
         return jpegamd_fail("compress_image: out of device memory");
     size_t cap = nb * 16 < nb * 64 ? nb * 16 : nb * 64; // a typical plane needs far fewer than 64 pairs per block
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (pairs.p) {
-            (void)hipFree(pairs.p);
-            pairs.p = nullptr;
-        }
-        if (pairs.alloc(cap * 8))
+        if (pairs.alloc(cap * 8)) // (a second attempt lets go of the first buffer)
             return jpegamd_fail("compress_image: out of device memory");
         if (jpegamd_rle_encode_plane_dev(d_coef, nb, pairs.as<int32_t>(), cap, offs.as<uint32_t>(), work.p, wbytes,
                                          nullptr))
@@ -123,6 +113,39 @@ int plane_code(const int16_t *d_coef, size_t nb, JpegamdPlaneCode &code)
     return jpegamd_fail("compress_image: run-length pass did not converge");
 }
 
+} // namespace
+
+JpegamdArena *&jpegamd_thread_arena()
+{
+    static thread_local JpegamdArena *arena = nullptr;
+    return arena;
+}
+
+// SURVEY 8b's context: a device and the device buffers of the host-pointer calls, kept from
+// call to call.  One call at a time per context (a mutex serialises them).
+struct jpegamd_context {
+    int device = 0;
+    std::mutex mu;
+    JpegamdArena arena;
+};
+
+namespace {
+// runs `body` on the context's device with the context's buffers
+template <class Body> int in_context(jpegamd_context *ctx, const char *what, Body body)
+{
+    if (!ctx)
+        return jpegamd_fail("%s: null context", what);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int before = 0;
+    JPEGAMD_HIPCHK(hipGetDevice(&before));
+    JPEGAMD_HIPCHK(hipSetDevice(ctx->device));
+    ctx->arena.rewind();
+    jpegamd_thread_arena() = &ctx->arena;
+    const int rc = jpegamd_guarded(what, body);
+    jpegamd_thread_arena() = nullptr;
+    (void)hipSetDevice(before);
+    return rc;
+}
 } // namespace
 
 extern "C" {
@@ -313,6 +336,54 @@ int jpegamd_decompress_image(const uint8_t *bin, size_t len, const int32_t q_lum
                              uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows, int *cols)
 {
     return jpegamd_guarded("decompress_image", [&] { return decompress_image_impl(bin, len, q_luma, q_chroma, bgr, cap_bytes, stride, rows, cols); });
+}
+
+int jpegamd_context_create(int device, jpegamd_context **ctx)
+{
+    if (!ctx)
+        return jpegamd_fail("context_create: null pointer");
+    *ctx = nullptr;
+    int before = 0;
+    JPEGAMD_HIPCHK(hipGetDevice(&before));
+    if (jpegamd_init(device)) // checks the device, selects it, creates the copier's staging buffers
+        return 1;
+    (void)hipSetDevice(before);
+    jpegamd_context *c = new (std::nothrow) jpegamd_context;
+    if (!c)
+        return jpegamd_fail("context_create: out of host memory");
+    c->device = device;
+    *ctx = c;
+    return 0;
+}
+
+void jpegamd_context_destroy(jpegamd_context *ctx)
+{
+    if (!ctx)
+        return;
+    int before = 0;
+    const bool have = hipGetDevice(&before) == hipSuccess;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    ctx->arena.release();
+    if (have)
+        (void)hipSetDevice(before);
+    delete ctx;
+}
+
+int jpegamd_context_compress_image(jpegamd_context *ctx, const uint8_t *bgr, int rows, int cols, size_t stride,
+                                   const int32_t q_luma[64], const int32_t q_chroma[64], uint8_t **bin, size_t *bin_len)
+{
+    return in_context(ctx, "compress_image",
+                      [&] { return compress_image_impl(bgr, rows, cols, stride, q_luma, q_chroma, bin, bin_len); });
+}
+
+int jpegamd_context_decompress_image(jpegamd_context *ctx, const uint8_t *bin, size_t len, const int32_t q_luma[64],
+                                     const int32_t q_chroma[64], uint8_t *bgr, size_t cap_bytes, size_t stride, int *rows,
+                                     int *cols)
+{
+    return in_context(ctx, "decompress_image", [&] {
+        return decompress_image_impl(bin, len, q_luma, q_chroma, bgr, cap_bytes, stride, rows, cols);
+    });
 }
 
 } // extern "C"

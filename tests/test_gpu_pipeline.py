@@ -82,3 +82,25 @@ def test_host_pointer_entry_points_with_row_pitch(gpu):
     rec = jpeg_amd.decode_image(*want, rows, cols, qy, qc).cpu().numpy()
     assert np.array_equal(out[:, :cols * 3].reshape(rows, cols, 3), rec)
     assert (out[:, cols * 3:] == 0xCD).all()  # the padding of every row is left alone
+
+
+def test_context_keeps_buffers_and_gives_the_same_bytes(gpu):
+    """jpegamd_context_*: the host-pointer calls with device buffers kept between calls
+    (SURVEY 8b).  Images of growing and shrinking sizes through one context give the bytes
+    and pixels of the plain calls; a second context on the same device is independent."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    qy, qc = jpeg_amd.quality_tables(60)
+    with jpeg_amd.Context(0) as ctx, jpeg_amd.Context(0) as other:
+        for i, (rows, cols, kind) in enumerate([(64, 528, "photo"), (256, 1024, "noise"), (32, 48, "photo"),
+                                                (256, 1024, "photo"), (16, 16, "gray")]):
+            img = synth_image(rows, cols, 40 + i, kind).numpy()
+            want = jpeg_amd.compress_image(img, qy, qc)
+            got = ctx.compress_image(img, qy, qc)
+            assert got == want, (rows, cols)
+            rec = ctx.decompress_image(got, qy, qc)
+            assert np.array_equal(rec, jpeg_amd.decompress_image(want, qy, qc))
+            if i == 1:
+                assert other.compress_image(img, qy, qc) == want
+    with pytest.raises(jpeg_amd.JpegAmdError):
+        jpeg_amd.Context(99)

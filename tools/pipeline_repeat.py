@@ -16,3 +16,10 @@ for i in range(6):
     t0 = time.perf_counter(); data = jpeg_amd.compress_image(himg, qy, qc); t1 = time.perf_counter()
     rec = jpeg_amd.decompress_image(data, qy, qc); t2 = time.perf_counter()
     print(f"call {i}: image -> .bin {1e3 * (t1 - t0):6.2f} ms   .bin -> image {1e3 * (t2 - t1):6.2f} ms   ({len(data)} bytes)")
+with jpeg_amd.Context(0) as ctx:  # the same through a context: device buffers kept between calls, output array reused
+    out = np.empty_like(himg)
+    for i in range(6):
+        t0 = time.perf_counter(); d2 = ctx.compress_image(himg, qy, qc); t1 = time.perf_counter()
+        ctx.decompress_image(d2, qy, qc, out=out); t2 = time.perf_counter()
+        print(f"context call {i}: image -> .bin {1e3 * (t1 - t0):6.2f} ms   .bin -> image {1e3 * (t2 - t1):6.2f} ms")
+    assert d2 == data and np.array_equal(out, rec)
