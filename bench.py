@@ -96,6 +96,44 @@ def run_as_launcher(n, argv):
     return rc
 
 
+def rle_variant(lib, _lib, torch, dev, stream, enc_args, coefs, rows, cols, iters):
+    """jpegamd_encode_image_rle_dev: encode_image_kernel (writing one pair count per block beside
+    the coefficients) followed by the run-length kernels of the three planes, timed with events on
+    the stream they are launched on.  Algorithmic bytes of the run-length stage: the 3 B/px of
+    coefficients read once, 8 B per (value, run) pair + 4 B per block offset written."""
+    nbs = [int(c.shape[0]) for c in coefs]
+    work = torch.empty(lib.jpegamd_rle_workspace_bytes(sum(nbs)) + 256, dtype=torch.uint8, device=dev)
+    wptr = (work.data_ptr() + 255) & ~255
+    offs = [torch.empty(nb + 1, dtype=torch.int32, device=dev) for nb in nbs]
+    caps = [nb * 16 for nb in nbs]
+    pairs = [torch.empty((cap, 2), dtype=torch.int32, device=dev) for cap in caps]
+    arr = lambda vals, t: (t * 3)(*vals)
+    args = enc_args[:6] + (arr([c.data_ptr() for c in coefs], ctypes.c_void_p),
+                           arr([p.data_ptr() for p in pairs], ctypes.c_void_p), arr(caps, ctypes.c_size_t),
+                           arr([o.data_ptr() for o in offs], ctypes.c_void_p), wptr, work.numel() - 256, stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    for _ in range(3):
+        _lib.check(lib.jpegamd_encode_image_rle_dev(*args))
+    for i in range(iters):
+        ev[i].record()
+        _lib.check(lib.jpegamd_encode_image_rle_dev(*args))
+    ev[iters].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))[iters // 2]
+    totals = [int(o[nb].item()) & 0xFFFFFFFF for o, nb in zip(offs, nbs)]
+    if any(t > c for t, c in zip(totals, caps)):
+        return {"error": "pair buffers too small for this image", "pairs": totals}
+    npix = rows * cols
+    nbytes = 6.0 * npix + sum(nbs) + 3.0 * npix + 8.0 * sum(totals) + 4.0 * sum(nbs)
+    return {"workload": "fused encode + (value, run) pairs of the three planes (jpegamd_encode_image_rle_dev)",
+            "ms": ms, "pairs": totals, "pairs_per_block": sum(totals) / sum(nbs),
+            "algorithmic_bytes": nbytes, "GBs": nbytes / (ms * 1e-3) / 1e9,
+            "frac_of_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "Mpixel_s": npix / (ms * 1e-3) / 1e6,
+            "timing": "median of per-call intervals between torch events on the launching stream (four kernels "
+                      "and their launch gaps); per-kernel durations: profiles/"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +250,14 @@ def main():
                  "kernels_Mpixel_s": rows * cols / ((n_enc + n_dec) * 1e-3) / 1e6}
         del noise
 
+    # Variant with the run-length stage on the device behind the encoder (north_star's
+    # "zigzag/run-length packing"): fused encode -> one-launch (value, run) pair emission for the
+    # three planes.  Its written bytes are data dependent, so it is reported on its own and never
+    # mixed into `value`.
+    rle = None
+    if world == 1:
+        rle = rle_variant(lib, _lib, torch, dev, stream, enc_args, coefs, rows, cols, max(10, args.steps))
+
     if rank == 0:
         dominant = "encode_image_kernel" if enc_ms >= dec_ms else "decode_image_kernel"
         ach = enc_gbs if enc_ms >= dec_ms else dec_gbs
@@ -245,6 +291,8 @@ def main():
         }
         if worst is not None:
             line["worst_case_input"] = worst
+        if rle is not None:
+            line["rle_variant"] = rle
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N=1 figure
             # bounded sample: about 20 s of single-thread oracle work = one whole 8192^2 image
             crop_r, crop_c = min(rows, 8192), min(cols, 8192)

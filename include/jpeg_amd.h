@@ -106,15 +106,35 @@ size_t jpegamd_rle_workspace_bytes(size_t nb);
  * block b's first pair, d_block_offsets[nb] = total number of pairs (nb + 1 uint32).
  * Pairs beyond cap_pairs are not written (the total still is): size the buffer
  * for nb*64 pairs, or call again when the total exceeds the capacity.
- * DEVICE pointers, three launches on `stream`, no allocation. */
+ * DEVICE pointers, three launches on `stream` (pairs per 256 blocks, scan, emit), no allocation. */
 int jpegamd_rle_encode_plane_dev(const int16_t *d_coef_zz, size_t nb, int32_t *d_pairs, size_t cap_pairs,
                                  uint32_t *d_block_offsets, void *d_workspace, size_t workspace_bytes,
                                  void *stream);
+/* The three planes of an image (mainEncode's three encodeChannel calls, encode_decode.cpp:
+ * 1327-1329) in ONE launch: arrays of three device pointers / sizes, one workspace of
+ * jpegamd_rle_workspace_bytes(nb[0] + nb[1] + nb[2]) bytes. */
+int jpegamd_rle_encode_image_dev(const int16_t *const d_coef_zz[3], const size_t nb[3], int32_t *const d_pairs[3],
+                                 const size_t cap_pairs[3], uint32_t *const d_block_offsets[3], void *d_workspace,
+                                 size_t workspace_bytes, void *stream);
+/* jpegamd_encode_image_dev followed by the run-length stage of its three planes
+ * (encodeChannelGPU up to and including run_length_encode, encode_decode.cpp:720-751, for Y, Cb
+ * and Cr) with the per-block pair counts handed over from the encoder's registers, so the
+ * run-length kernels read the coefficient planes once.  Outputs as the two calls made
+ * separately: d_coef[3] (kept: the decoder or a caller may want them), d_pairs[3],
+ * d_block_offsets[3].  Workspace: jpegamd_rle_workspace_bytes(blocks of the three planes
+ * together) bytes, 256-byte aligned.  Four launches on `stream`, no allocation. */
+int jpegamd_encode_image_rle_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
+                                 const int32_t q_chroma[64], int16_t *const d_coef[3], int32_t *const d_pairs[3],
+                                 const size_t cap_pairs[3], uint32_t *const d_block_offsets[3], void *d_workspace,
+                                 size_t workspace_bytes, void *stream);
 /* decodeRLE, encode_decode.cpp:484-518: n_pairs (value, run) int32 pairs expanded
  * into one sequence cut every 64 values -> nb x 64 int16.  Values that would fall
  * beyond block nb-1 are dropped (the trailing pad symbols of loadEncodedData,
  * encode_decode.cpp:1261-1263, which the reference discards at :702); blocks the
- * stream does not reach are zero; non-positive runs expand to nothing. */
+ * stream does not reach are zero; non-positive runs expand to nothing.  Run lengths are
+ * untrusted (they come from a file): any run is treated as min(run, nb*64 + 1) and positions
+ * are 64-bit, so an oversized run fills to the end of the plane and everything after it is
+ * dropped, as the reference's expand-then-cut would, in bounded time. */
 int jpegamd_rle_decode_plane_dev(const int32_t *d_pairs, size_t n_pairs, size_t nb, int16_t *d_coef_zz,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
 

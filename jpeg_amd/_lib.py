@@ -32,6 +32,11 @@ SIGNATURES = {
                              _c.c_void_p, _c.c_void_p, _c.c_size_t],
     "jpegamd_rle_encode_plane_dev": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                      _c.c_size_t, _c.c_void_p],
+    "jpegamd_rle_encode_image_dev": [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                     _c.c_size_t, _c.c_void_p],
+    "jpegamd_encode_image_rle_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                                     _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
+                                     _c.c_void_p],
     "jpegamd_rle_decode_plane_dev": [_c.c_void_p, _c.c_size_t, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                      _c.c_size_t, _c.c_void_p],
     "jpegamd_bin_encode": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
@@ -59,6 +64,9 @@ SIGNATURES = {
                                _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                _c.POINTER(_c.c_float), _c.POINTER(_c.c_float)],
 }
+
+# the exported functions that do not return an int status (set up by hand in load())
+OTHER_RETURN_TYPES = ("jpegamd_last_error", "jpegamd_rle_workspace_bytes", "jpegamd_free", "jpegamd_context_destroy")
 
 _lib = None
 

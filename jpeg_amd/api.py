@@ -186,25 +186,84 @@ def time_image(bgr, coefs, bgr_out, q_luma, q_chroma, iters, stream=None):
     return e.value, d.value
 
 
+def _sync(stream):
+    import torch
+    if stream is None:
+        torch.cuda.current_stream().synchronize()
+    else:
+        torch.cuda.ExternalStream(int(stream)).synchronize()
+
+
 def rle_encode_plane(coef, stream=None):
     """run_length_encode over a zigzag coefficient plane (encode_decode.cpp:350-373,
     :643-645): cuda int16 [nb, 64] -> (pairs cuda int32 [n, 2] = (value, run),
     block_offsets cuda int32 [nb + 1]) via jpegamd_rle_encode_plane_dev."""
+    (pairs, offs), = rle_encode_planes([coef], stream=stream)
+    return pairs, offs
+
+
+def rle_encode_planes(coefs, stream=None):
+    """The same for one plane (jpegamd_rle_encode_plane_dev) or the three planes of an image in
+    ONE launch (jpegamd_rle_encode_image_dev): list of cuda int16 [nb, 64] -> list of
+    (pairs, block_offsets)."""
     import torch
     lib = _lib.load()
-    nb = int(coef.shape[0])
-    src = _dev(coef, torch.int16, "rle_encode_plane")
-    work = torch.empty(lib.jpegamd_rle_workspace_bytes(nb), dtype=torch.uint8, device=coef.device)
-    offs = torch.empty(nb + 1, dtype=torch.int32, device=coef.device)
-    cap = min(nb * 64, max(1024, nb * 12))  # typical planes need far less than the worst case
+    if len(coefs) not in (1, 3):
+        raise ValueError("rle_encode_planes: one plane or three")
+    nbs = [int(c.shape[0]) for c in coefs]
+    srcs = [_dev(c, torch.int16, "rle_encode_planes") for c in coefs]
+    dev = coefs[0].device
+    work = torch.empty(lib.jpegamd_rle_workspace_bytes(sum(nbs)), dtype=torch.uint8, device=dev)
+    offs = [torch.empty(nb + 1, dtype=torch.int32, device=dev) for nb in nbs]
+    caps = [min(nb * 64, max(1024, nb * 12)) for nb in nbs]  # typical planes need far less than the worst case
     while True:
-        pairs = torch.empty((cap, 2), dtype=torch.int32, device=coef.device)
-        _lib.check(lib.jpegamd_rle_encode_plane_dev(src, nb, pairs.data_ptr(), cap, offs.data_ptr(),
-                                                    work.data_ptr(), work.numel(), _stream(stream)))
-        total = int(offs[nb].item()) & 0xFFFFFFFF
-        if total <= cap:
-            return pairs[:total], offs
-        cap = total
+        pairs = [torch.empty((cap, 2), dtype=torch.int32, device=dev) for cap in caps]
+        if len(coefs) == 1:
+            _lib.check(lib.jpegamd_rle_encode_plane_dev(srcs[0], nbs[0], pairs[0].data_ptr(), caps[0],
+                                                        offs[0].data_ptr(), work.data_ptr(), work.numel(),
+                                                        _stream(stream)))
+        else:
+            arr = lambda vals, t: (t * 3)(*vals)
+            _lib.check(lib.jpegamd_rle_encode_image_dev(
+                arr(srcs, ctypes.c_void_p), arr(nbs, ctypes.c_size_t),
+                arr([p.data_ptr() for p in pairs], ctypes.c_void_p), arr(caps, ctypes.c_size_t),
+                arr([o.data_ptr() for o in offs], ctypes.c_void_p), work.data_ptr(), work.numel(), _stream(stream)))
+        _sync(stream)  # the totals are read on the host: wait for the stream the kernels ran on
+        totals = [int(o[nb].item()) & 0xFFFFFFFF for o, nb in zip(offs, nbs)]
+        if all(t <= c for t, c in zip(totals, caps)):
+            return [(p[:t], o) for p, t, o in zip(pairs, totals, offs)]
+        caps = [max(t, c) for t, c in zip(totals, caps)]
+
+
+def encode_image_rle(bgr, q_luma, q_chroma, stream=None):
+    """jpegamd_encode_image_rle_dev: fused encode + run-length stage of the three planes, the
+    pair counts handed from the encoder to the run-length kernels.  Returns
+    ((coef_y, coef_cb, coef_cr), [(pairs, block_offsets)] * 3)."""
+    import torch
+    lib = _lib.load()
+    rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
+    src = _dev(bgr, torch.uint8, "encode_image_rle")
+    dev = bgr.device
+    nbs = [(rows // 8) * (cols // 8)] + [(rows // 16) * (cols // 16)] * 2
+    coefs = tuple(torch.empty((n, 64), dtype=torch.int16, device=dev) for n in nbs)
+    work = torch.empty(lib.jpegamd_rle_workspace_bytes(sum(nbs)) + 256, dtype=torch.uint8, device=dev)
+    wptr = (work.data_ptr() + 255) & ~255
+    offs = [torch.empty(nb + 1, dtype=torch.int32, device=dev) for nb in nbs]
+    caps = [min(nb * 64, max(1024, nb * 12)) for nb in nbs]
+    ql, pl = _q(q_luma)
+    qc, pc = _q(q_chroma)
+    arr = lambda vals, t: (t * 3)(*vals)
+    while True:
+        pairs = [torch.empty((cap, 2), dtype=torch.int32, device=dev) for cap in caps]
+        _lib.check(lib.jpegamd_encode_image_rle_dev(
+            src, rows, cols, cols * 3, pl, pc, arr([c.data_ptr() for c in coefs], ctypes.c_void_p),
+            arr([p.data_ptr() for p in pairs], ctypes.c_void_p), arr(caps, ctypes.c_size_t),
+            arr([o.data_ptr() for o in offs], ctypes.c_void_p), wptr, work.numel() - 256, _stream(stream)))
+        _sync(stream)
+        totals = [int(o[nb].item()) & 0xFFFFFFFF for o, nb in zip(offs, nbs)]
+        if all(t <= c for t, c in zip(totals, caps)):
+            return coefs, [(p[:t], o) for p, t, o in zip(pairs, totals, offs)]
+        caps = [max(t, c) for t, c in zip(totals, caps)]
 
 
 def rle_decode_plane(pairs, nb, stream=None):

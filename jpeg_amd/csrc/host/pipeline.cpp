@@ -79,38 +79,59 @@ bool entropy_on_host()
     return e && std::strcmp(e, "host") == 0;
 }
 
-// run-length stage and entropy stage of one device coefficient plane
-int plane_code(const int16_t *d_coef, size_t nb, JpegamdPlaneCode &code)
+// fused encode + run-length stage (jpegamd_encode_image_rle_dev) and entropy stage
+int image_code(const uint8_t *d_bgr, int rows, int cols, const int32_t q_luma[64], const int32_t q_chroma[64],
+               int16_t *const d_coef[3], const size_t nb[3], JpegamdPlaneCode code[3], StageTrace &trace)
 {
-    DevMem work, offs, pairs;
-    const size_t wbytes = jpegamd_rle_workspace_bytes(nb);
-    if (work.alloc(wbytes) || offs.alloc((nb + 1) * sizeof(uint32_t)))
+    DevMem work, offs[3], pairs[3];
+    const size_t wbytes = jpegamd_rle_workspace_bytes(nb[0] + nb[1] + nb[2]);
+    if (work.alloc(wbytes))
         return jpegamd_fail("compress_image: out of device memory");
-    size_t cap = nb * 16 < nb * 64 ? nb * 16 : nb * 64; // a typical plane needs far fewer than 64 pairs per block
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (pairs.alloc(cap * 8)) // (a second attempt lets go of the first buffer)
+    size_t cap[3];
+    for (int k = 0; k < 3; ++k) {
+        cap[k] = nb[k] * 16 < nb[k] * 64 ? nb[k] * 16 : nb[k] * 64; // a typical plane needs far fewer than 64 pairs per block
+        if (offs[k].alloc((nb[k] + 1) * sizeof(uint32_t)))
             return jpegamd_fail("compress_image: out of device memory");
-        if (jpegamd_rle_encode_plane_dev(d_coef, nb, pairs.as<int32_t>(), cap, offs.as<uint32_t>(), work.p, wbytes,
-                                         nullptr))
-            return 1;
-        uint32_t total = 0;
-        JPEGAMD_HIPCHK(hipMemcpy(&total, offs.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost));
-        if (total <= cap) {
-            if (!entropy_on_host()) {
-                const int rc = jpegamd_device_encode_plane(pairs.as<int32_t>(), (size_t)total * 2, code);
-                if (rc != 2)
-                    return rc;
-            }
-            HostSymbols sym; // the host path: the pairs are the memory of the reference's std::vector<int>
-            if (!sym.resize((size_t)total * 2))
-                return jpegamd_fail("compress_image: out of host memory");
-            if (total && jpegamd_staged_copy_linear(pairs.p, sym.data(), (size_t)total * 8, false))
-                return 1;
-            return jpegamd_host_encode_plane(sym.data(), sym.size(), code);
-        }
-        cap = total;
     }
-    return jpegamd_fail("compress_image: run-length pass did not converge");
+    uint32_t total[3] = {0, 0, 0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int k = 0; k < 3; ++k)
+            if (pairs[k].alloc(cap[k] * 8)) // (a second attempt lets go of the first buffer)
+                return jpegamd_fail("compress_image: out of device memory");
+        int32_t *const pp[3] = {pairs[0].as<int32_t>(), pairs[1].as<int32_t>(), pairs[2].as<int32_t>()};
+        uint32_t *const po[3] = {offs[0].as<uint32_t>(), offs[1].as<uint32_t>(), offs[2].as<uint32_t>()};
+        if (jpegamd_encode_image_rle_dev(d_bgr, rows, cols, (size_t)cols * 3, q_luma, q_chroma, d_coef, pp, cap, po, work.p,
+                                         wbytes, nullptr))
+            return 1;
+        bool fits = true;
+        for (int k = 0; k < 3; ++k) {
+            JPEGAMD_HIPCHK(hipMemcpy(&total[k], po[k] + nb[k], 4, hipMemcpyDeviceToHost));
+            if (total[k] > cap[k])
+                fits = false, cap[k] = total[k];
+        }
+        if (fits)
+            break;
+        if (attempt == 1)
+            return jpegamd_fail("compress_image: run-length pass did not converge");
+    }
+    trace.mark("transform+run-length");
+    for (int k = 0; k < 3; ++k) {
+        if (!entropy_on_host()) {
+            const int rc = jpegamd_device_encode_plane(pairs[k].as<int32_t>(), (size_t)total[k] * 2, code[k]);
+            if (rc == 0)
+                continue;
+            if (rc != 2)
+                return rc;
+        }
+        HostSymbols sym; // the host path: the pairs are the memory of the reference's std::vector<int>
+        if (!sym.resize((size_t)total[k] * 2))
+            return jpegamd_fail("compress_image: out of host memory");
+        if (total[k] && jpegamd_staged_copy_linear(pairs[k].p, sym.data(), (size_t)total[k] * 8, false))
+            return 1;
+        if (jpegamd_host_encode_plane(sym.data(), sym.size(), code[k]))
+            return 1;
+    }
+    return 0;
 }
 
 } // namespace
@@ -218,15 +239,12 @@ static int compress_image_impl(const uint8_t *bgr, int rows, int cols, size_t st
     if (jpegamd_staged_copy(d_bgr.p, const_cast<uint8_t *>(bgr), stride, (size_t)cols * 3, rows, true))
         return 1;
     trace.mark("upload");
-    if (jpegamd_encode_image_dev(d_bgr.as<uint8_t>(), rows, cols, (size_t)cols * 3, q_luma, q_chroma,
-                                 d_y.as<int16_t>(), d_cb.as<int16_t>(), d_cr.as<int16_t>(), nullptr))
-        return 1;
-    trace.mark("transform");
     JpegamdPlaneCode code[3];
-    if (plane_code(d_y.as<int16_t>(), nby, code[0]) || plane_code(d_cb.as<int16_t>(), nbc, code[1]) ||
-        plane_code(d_cr.as<int16_t>(), nbc, code[2]))
+    int16_t *const d_coef[3] = {d_y.as<int16_t>(), d_cb.as<int16_t>(), d_cr.as<int16_t>()};
+    const size_t nbs[3] = {nby, nbc, nbc};
+    if (image_code(d_bgr.as<uint8_t>(), rows, cols, q_luma, q_chroma, d_coef, nbs, code, trace))
         return 1;
-    trace.mark("run-length+entropy");
+    trace.mark("entropy");
     size_t need = 0;
     (void)jpegamd_bin_assemble(code, rows, cols, rows / 2, cols / 2, nullptr, 0, &need); // sizing call
     uint8_t *buf = static_cast<uint8_t *>(std::malloc(need ? need : 1));

@@ -39,6 +39,12 @@ template <class Body> int jpegamd_guarded(const char *what, Body body) noexcept
 // the copier's pinned buffers and streams for the current device, ahead of the first copy (jpegamd_init)
 __attribute__((visibility("hidden"))) int jpegamd_staged_copy_warm();
 
+// run-length stage of three planes whose per-block pair counts the encoder has written
+// (rle_kernels.hip); `sums` = one uint32 of device memory per 256 blocks of each plane
+__attribute__((visibility("hidden"))) int jpegamd_rle_encode_counted(
+    int16_t *const coef[3], const size_t nb[3], const uint8_t *const counts[3], int32_t *const pairs[3],
+    const size_t cap_pairs[3], uint32_t *const block_offsets[3], uint32_t *sums, void *stream);
+
 #define JPEGAMD_HIPCHK(expr)                                                                          \
     do {                                                                                              \
         hipError_t e_ = (expr);                                                                       \

@@ -162,6 +162,25 @@ __device__ __forceinline__ void stage_read_dequant(const uint8_t *stage, int lan
     }
 }
 
+// Bit i of the result is set where position i is the LAST of its run in the block's zigzag
+// sequence: value i differs from value i + 1, or i == 63 (encode_decode.cpp:357-368).  The
+// number of (value, run) pairs is the popcount; the runs are the distances between set bits.
+__device__ __forceinline__ unsigned long long run_ends(const uint32_t (&w)[32])
+{
+    uint32_t half[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 31; k >= 0; --k) { // MSB first: each step doubles the half-mask and adds one bit
+        // low half: value 2k ^ value 2k+1, high half: value 2k+1 ^ value 2k+2
+        const uint32_t x = w[k] ^ __builtin_amdgcn_alignbit(k < 31 ? w[k + 1] : 0u, w[k], 16);
+        const uint32_t odd = k == 31 ? 1u : (uint32_t)(x > 0xFFFFu);
+        const uint32_t even = (uint32_t)((x & 0xFFFFu) != 0u);
+        uint32_t &h = half[k >> 4];
+        h = h + h + odd;
+        h = h + h + even;
+    }
+    return ((unsigned long long)half[1] << 32) | half[0];
+}
+
 // One task of the colour stage for one lane: 2 rows x 4 pixels of BGR -> the eight luma
 // values as magic floats (byte in the low 8 bits) and the two quads' sums of centred Cb, Cr
 // (RGB2YCbCr, encode_decode.cpp:39-75, and the sums of chromaSubsampling, :139-149).

@@ -40,10 +40,17 @@ namespace {
 
 // ------------------------------------------------------------- fused encoder
 // grid: one wave per 512x16 tile, 4 waves per workgroup.
+// kCounts: also write, per block, the number of (value, run) pairs run_length_encode
+// (encode_decode.cpp:350-373) will make of it -- the lane has the 64 quantised values in
+// registers, so the run-length stage need not read the planes a second time for its offsets.
+struct CountPlanes {
+    uint8_t *y, *cb, *cr; // one byte per block, raster order like the coefficient planes
+};
+template <bool kCounts>
 __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
     int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
-    int tiles_x, int n_tiles)
+    int tiles_x, int n_tiles, CountPlanes counts)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kWaveLds];
     // quantiser multipliers as an LDS table (broadcast b128 reads): 128 SGPRs of
@@ -191,6 +198,22 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
             // the writes below; the fence only pins the compiler's order.
             wave_lds_fence();
             stage_write_zigzag(v, stage, lane);
+            if constexpr (kCounts) {
+                // pairs of this block = run ends of its zigzag sequence (:357-368).  Counted on the
+                // staged block read back (the 64 values are dead by now: counting them in registers
+                // before the staging costs the kernel its third wave per SIMD)
+                wave_lds_fence();
+                uint32_t w[32];
+                const uint4 *own = reinterpret_cast<const uint4 *>(stage + lane * kStagePitch);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint4 d = own[k];
+                    w[4 * k] = d.x, w[4 * k + 1] = d.y, w[4 * k + 2] = d.z, w[4 * k + 3] = d.w;
+                }
+                uint8_t *dst = luma ? counts.y + (size_t)(ty * 2 + it) * bw_y + bcol
+                                    : (lane < 32 ? counts.cb : counts.cr) + (size_t)ty * bw_c + bcol;
+                *dst = (uint8_t)__builtin_popcountll(run_ends(w));
+            }
         }
         wave_lds_fence();
 
@@ -610,7 +633,8 @@ int jpegamd_init(int device)
 // dispatch packet's, what rocprofv3 reports too) are recorded into them
 static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
                                const int32_t q_chroma[64], int16_t *d_coef_y, int16_t *d_coef_cb,
-                               int16_t *d_coef_cr, void *stream, hipEvent_t start, hipEvent_t stop)
+                               int16_t *d_coef_cr, void *stream, hipEvent_t start, hipEvent_t stop,
+                               const CountPlanes *counts = nullptr)
 {
     QuantPair qp;
     if (check_image(d_bgr, rows, cols, stride, "encode_image") || make_consts(q_luma, qp.t[0], "encode_image") ||
@@ -621,12 +645,20 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
     const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
     const int n_tiles = tiles_x * (rows / 16);
     const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    if (counts) {
+        hipExtLaunchKernelGGL(encode_image_kernel<true>, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
+                              start, stop, 0, d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x,
+                              n_tiles, *counts);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const Transform tr = transform_choice();
     if (tr != Transform::valu)
         return jpegamd_launch_encode_variant(tr == Transform::mfma_f32 ? 1 : 2, grid, stream, start, stop, d_bgr, rows,
                                              cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
-    hipExtLaunchKernelGGL(encode_image_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop,
-                          0, d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
+    hipExtLaunchKernelGGL(encode_image_kernel<false>, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start,
+                          stop, 0, d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles,
+                          CountPlanes{nullptr, nullptr, nullptr});
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -656,6 +688,32 @@ int jpegamd_encode_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t st
 {
     return launch_encode_image(d_bgr, rows, cols, stride, q_luma, q_chroma, d_coef_y, d_coef_cb, d_coef_cr, stream,
                                nullptr, nullptr);
+}
+
+int jpegamd_encode_image_rle_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
+                                 const int32_t q_chroma[64], int16_t *const d_coef[3], int32_t *const d_pairs[3],
+                                 const size_t cap_pairs[3], uint32_t *const d_block_offsets[3], void *d_workspace,
+                                 size_t workspace_bytes, void *stream)
+{
+    if (!d_coef || !d_pairs || !cap_pairs || !d_block_offsets || !d_workspace)
+        return fail("encode_image_rle: null pointer");
+    if (rows <= 0 || cols <= 0 || (rows & 15) || (cols & 15))
+        return fail("encode_image_rle: rows=%d cols=%d must be positive multiples of 16", rows, cols);
+    const size_t nby = (size_t)(rows / 8) * (cols / 8), nbc = (size_t)(rows / 16) * (cols / 16);
+    const size_t nb[3] = {nby, nbc, nbc};
+    if (workspace_bytes < jpegamd_rle_workspace_bytes(nby + 2 * nbc) || (reinterpret_cast<uintptr_t>(d_workspace) & 255))
+        return fail("encode_image_rle: workspace of %zu bytes (need %zu, 256-byte aligned)", workspace_bytes,
+                    jpegamd_rle_workspace_bytes(nby + 2 * nbc));
+    // workspace: the three count arrays (one byte per block, each 256-byte aligned), then the tile sums
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    uint8_t *w = static_cast<uint8_t *>(d_workspace);
+    const CountPlanes cp{w, w + up(nby), w + up(nby) + up(nbc)};
+    uint32_t *sums = reinterpret_cast<uint32_t *>(w + up(nby) + 2 * up(nbc));
+    if (launch_encode_image(d_bgr, rows, cols, stride, q_luma, q_chroma, d_coef[0], d_coef[1], d_coef[2], stream, nullptr,
+                            nullptr, &cp))
+        return 1;
+    const uint8_t *const counts[3] = {cp.y, cp.cb, cp.cr};
+    return jpegamd_rle_encode_counted(d_coef, nb, counts, d_pairs, cap_pairs, d_block_offsets, sums, stream);
 }
 
 int jpegamd_decode_image_dev(const int16_t *d_coef_y, const int16_t *d_coef_cb, const int16_t *d_coef_cr,

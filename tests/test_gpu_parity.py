@@ -157,6 +157,53 @@ def test_image_of_exact_ties_only(gpu, orc, model):
         _check_coef(g, w, f"ties {n}")
 
 
+def test_fused_decoder_colour_stage_is_bit_exact_on_its_own_planes(gpu, orc):
+    """the +-2 allowed on B,G,R above must be nothing but one chroma (or luma)
+    LSB carried through YCbCr2RGB.  Proof: the fused decoder's pixels equal, BIT FOR BIT,
+    the oracle's upsampleChroma + YCbCr2RGB (encode_decode.cpp:154-173, 77-114) applied to the
+    planes the GPU's own per-plane decoder produces from the same coefficients (same IDCT code,
+    tested at +-1 against the oracle elsewhere).  The first image makes every one of the 65 536
+    (Cb, Cr) pairs appear under random luma: DC-only chroma blocks at QF=100 (Q = 1) decode to
+    the constant DC/8 + 128, one pair per MCU of a 4096^2 image."""
+    import torch
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+
+    def check(cy, ccb, ccr, rows, cols, qy, qc, what):
+        fused = jpeg_amd.decode_image(cy, ccb, ccr, rows, cols, qy, qc).cpu().numpy()
+        y = jpeg_amd.decode_plane(cy, rows, cols, qy).cpu().numpy()
+        cb = jpeg_amd.decode_plane(ccb, rows // 2, cols // 2, qc).cpu().numpy()
+        cr = jpeg_amd.decode_plane(ccr, rows // 2, cols // 2, qc).cpu().numpy()
+        up = lambda c: np.repeat(np.repeat(c, 2, axis=0), 2, axis=1)  # upsampleChroma: (i/2, j/2)
+        ycc = np.ascontiguousarray(np.stack([y, up(cb), up(cr)], -1))
+        want = orc.ycbcr2rgb(ycc)
+        assert np.array_equal(fused, want), f"{what}: {(fused != want).sum()} samples differ"
+        return cb, cr
+
+    # all chroma pairs
+    rows = cols = 4096
+    q1 = np.ones(64, np.int32)
+    rng = np.random.default_rng(4)
+    nbc = (rows // 16) * (cols // 16)
+    pair = rng.permutation(65536)
+    ccb = np.zeros((nbc, 64), np.int16)
+    ccr = np.zeros((nbc, 64), np.int16)
+    ccb[:, 0] = ((pair >> 8) - 128) * 8
+    ccr[:, 0] = ((pair & 255) - 128) * 8
+    cy = np.zeros(((rows // 8) * (cols // 8), 64), np.int16)
+    cy[:, 0] = rng.integers(-1024, 1017, cy.shape[0])          # luma 0..255 in steps, plus texture below
+    cy[:, 1:6] = rng.integers(-60, 61, (cy.shape[0], 5))
+    cb, cr = check(_t(cy, gpu), _t(ccb, gpu), _t(ccr, gpu), rows, cols, q1, q1, "all chroma pairs")
+    seen = np.unique(cb[::8, ::8].astype(np.int32) * 256 + cr[::8, ::8])
+    assert seen.size == 65536, "the image was meant to hold every (Cb, Cr) pair"
+    # ordinary images, dense and sparse, through the encoder
+    for kind, seed, r, c, qf in (("photo", 31, 256, 1040, 50), ("noise", 32, 128, 512, 90), ("noise", 33, 64, 528, 10),
+                                 ("photo", 34, 48, 2064, 100)):
+        qy, qc = jpeg_amd.quality_tables(qf)
+        coefs = jpeg_amd.encode_image(synth_image(r, c, seed, kind, device=gpu), qy, qc)
+        check(*coefs, r, c, qy, qc, f"{kind} QF={qf}")
+
+
 def test_matrix_core_encoder_variant(gpu, orc, model, monkeypatch):
     """JPEGAMD_TRANSFORM=mfma: the opt-in encoder whose DCT runs as v_mfma_f32_16x16x4_f32
     chains.  An f32 MFMA is a k-ordered fma chain, so it must equal the host replay

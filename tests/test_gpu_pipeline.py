@@ -54,6 +54,32 @@ def test_pipeline_errors(gpu):
         jpeg_amd.decompress_image(b"\x00" * 20, qy, qc)
 
 
+def test_crafted_bin_with_oversized_runs_returns_quickly(gpu, orc):
+    """decompress_image accepts arbitrary bytes.  A .bin whose pair streams carry
+    runs of 2^31-1 (built with the oracle's container writer) must decode in bounded time with
+    the overflow dropped: plane = what the reference's expand-then-cut would keep."""
+    import time
+    import torch
+    import jpeg_amd
+    rows, cols = 64, 96
+    big = 2**31 - 1
+    nby, nbc = (rows // 8) * (cols // 8), (rows // 16) * (cols // 16)
+    sy = np.array([7, 3, 0, 61, -2, big, 9, big, 5, 64], np.int32)     # block 0, then -2 to the end of the plane
+    scb = np.array([1, big] * 200, np.int32)                             # every pair oversized
+    scr = np.array([0, 64] * nbc, np.int32)
+    data = orc.write_bin(sy, scb, scr, rows, cols)
+    qy, qc = jpeg_amd.quality_tables(50)
+    t0 = time.perf_counter()
+    rec = jpeg_amd.decompress_image(data, qy, qc)
+    assert time.perf_counter() - t0 < 10.0
+    cy = np.full((nby, 64), -2, np.int16)
+    cy[0, :3], cy[0, 3:] = 7, 0
+    ccb = np.full((nbc, 64), 1, np.int16)
+    ccr = np.zeros((nbc, 64), np.int16)
+    want = jpeg_amd.decode_image(*(torch.from_numpy(c).to(gpu) for c in (cy, ccb, ccr)), rows, cols, qy, qc)
+    assert np.array_equal(rec, want.cpu().numpy())
+
+
 def test_host_pointer_entry_points_with_row_pitch(gpu):
     """jpegamd_encode_image / jpegamd_decode_image on pageable host memory (the level-1 boundary
     of INTEGRATION.md): large enough for the staged copier, and with a row pitch wider than the

@@ -50,6 +50,45 @@ def test_rle_encode_matches_oracle(gpu, orc):
         assert counts.min() >= 1 and counts.max() <= 64, name
 
 
+def test_rle_encode_three_planes_in_one_launch(gpu, orc):
+    """jpegamd_rle_encode_image_dev: the look-back chain restarts at every plane's first
+    workgroup; planes of very different sizes, bit-exact vs the oracle and the per-plane call."""
+    import jpeg_amd
+    rng = np.random.default_rng(5)
+    def sparse(nb):
+        c = np.zeros((nb, 64), np.int16)
+        m = rng.random((nb, 64)) < 0.15
+        c[m] = rng.integers(-30, 31, size=int(m.sum()), dtype=np.int16)
+        return c
+    for nbs in ((70000, 300, 1), (1, 1, 1), (257, 256, 255), (5, 20000, 513)):
+        planes = [sparse(nb) for nb in nbs]
+        dev = [torch.from_numpy(p).to(gpu) for p in planes]
+        got = jpeg_amd.rle_encode_planes(dev)
+        for (pairs, offs), p, d in zip(got, planes, dev):
+            assert np.array_equal(pairs.cpu().numpy().reshape(-1), orc.rle_stream(p)), nbs
+            one_pairs, one_offs = jpeg_amd.rle_encode_plane(d)
+            assert torch.equal(one_pairs, pairs) and torch.equal(one_offs, offs)
+
+
+def test_fused_encode_with_run_length_stage(gpu, orc):
+    """jpegamd_encode_image_rle_dev: the encoder's per-block pair counts feed the run-length
+    kernels.  Same coefficient planes as the plain encoder, same pairs and offsets as the
+    separate run-length call, and the oracle's stream; ragged tile widths, dense and sparse."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    for kind, seed, rows, cols, qf in (("photo", 51, 256, 1040, 50), ("noise", 52, 64, 528, 100), ("photo", 53, 16, 16, 10),
+                                       ("gray", 54, 48, 2064, 90), ("noise", 55, 1024, 1024, 50)):
+        qy, qc = jpeg_amd.quality_tables(qf)
+        img = synth_image(rows, cols, seed, kind, device=gpu)
+        coefs, streams = jpeg_amd.encode_image_rle(img, qy, qc)
+        plain = jpeg_amd.encode_image(img, qy, qc)
+        for c, p in zip(coefs, plain):
+            assert torch.equal(c, p), (kind, rows, cols)
+        for (pairs, offs), (want_pairs, want_offs), c in zip(streams, jpeg_amd.rle_encode_planes(list(plain)), plain):
+            assert torch.equal(pairs, want_pairs) and torch.equal(offs, want_offs), (kind, rows, cols)
+            assert np.array_equal(pairs.cpu().numpy().reshape(-1), orc.rle_stream(c.cpu().numpy()))
+
+
 def test_rle_decode_matches_oracle(gpu, orc):
     import jpeg_amd
     rng = np.random.default_rng(7)
@@ -80,6 +119,53 @@ def test_rle_decode_loader_quirks(gpu, orc):
     assert np.array_equal(out, want)
     empty = jpeg_amd.rle_decode_plane(torch.empty((0, 2), dtype=torch.int32, device=gpu), 3)
     assert int(empty.abs().sum()) == 0
+
+
+def _expand(sym, nb):
+    """decodeRLE (encode_decode.cpp:484-518) + the drop of everything beyond the plane (:702),
+    with Python integers: the expected result for run lengths no vector could hold"""
+    flat = np.zeros(nb * 64, np.int16)
+    pos = 0
+    for v, r in np.asarray(sym, np.int64).reshape(-1, 2):
+        if r > 0:
+            if pos < flat.size:
+                flat[pos:min(pos + int(r), flat.size)] = v
+            pos += int(r)
+    return flat.reshape(nb, 64)
+
+
+def test_rle_decode_untrusted_run_lengths(gpu):
+    """runs come from a file.  Huge and negative runs must neither wrap positions
+    (values landing in the wrong blocks) nor keep the GPU busy: the overflow is dropped."""
+    import time
+    import jpeg_amd
+    big = 2**31 - 1
+    cases = [
+        (3, [5, big]),
+        (3, [1, 10, 7, big, 9, 5]),
+        (4, [0, big, 3, 4]),
+        (4, [2, 100, 4, -5, 6, big, 8, big, 9, 1]),
+        (2, [1, 127, 2, 2**31 - 1, 3, 2**31 - 1]),          # uint32 sums would wrap back into the plane
+        (5, [4, 65, 0, 70, -3, 200]),                          # long runs inside the plane (wave fill)
+    ]
+    for nb, sym in cases:
+        sym = np.array(sym, np.int32)
+        out = jpeg_amd.rle_decode_plane(torch.from_numpy(sym.reshape(-1, 2)).to(gpu), nb).cpu().numpy()
+        assert np.array_equal(out, _expand(sym, nb)), (nb, sym)
+    # a 1024^2 luma plane's worth of blocks and a million pairs with huge runs: seconds, not hours
+    nb = 16384
+    n = nb * 64
+    sym = np.empty((n, 2), np.int32)
+    sym[:, 0] = np.arange(n) % 50 + 1
+    sym[:, 1] = big
+    sym[0, 1] = 3
+    t0 = time.perf_counter()
+    out = jpeg_amd.rle_decode_plane(torch.from_numpy(sym).to(gpu), nb)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0
+    want = np.full(n, 2, np.int16)
+    want[:3] = 1
+    assert np.array_equal(out.cpu().numpy().reshape(-1), want)
 
 
 def test_lena_bin_through_device_rle(gpu, orc, lena_bgr):
