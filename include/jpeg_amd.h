@@ -127,6 +127,19 @@ int jpegamd_encode_image_rle_dev(const uint8_t *d_bgr, int rows, int cols, size_
                                  const int32_t q_chroma[64], int16_t *const d_coef[3], int32_t *const d_pairs[3],
                                  const size_t cap_pairs[3], uint32_t *const d_block_offsets[3], void *d_workspace,
                                  size_t workspace_bytes, void *stream);
+/* jpegamd_rle_encode_plane_dev for callers that cannot allocate or be handed a workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It
+ * has NO counterpart in the reference.  Same inputs, outputs and kernels; the per-workgroup
+ * counts live in a fixed device array inside the library (64.25 KiB per GPU, held until
+ * the process ends) instead of a workspace argument.  Calls no hipMalloc/hipFree or any
+ * allocating routine.  nb is limited to jpegamd_rle_noalloc_max_blocks() (4 Mi blocks, a
+ * 16384 x 16384 plane); larger planes are rejected with an error.  All calls on one GPU share
+ * that array: calls that overlap on one GPU (different streams or threads) race -- serialise
+ * them.  Nothing in the array needs to start at zero (every word read was written by the same
+ * call first). */
+int jpegamd_rle_encode_plane_noalloc_dev(const int16_t *d_coef_zz, size_t nb, int32_t *d_pairs, size_t cap_pairs,
+                                         uint32_t *d_block_offsets, void *stream);
+size_t jpegamd_rle_noalloc_max_blocks(void);
 /* decodeRLE, encode_decode.cpp:484-518: n_pairs (value, run) int32 pairs expanded
  * into one sequence cut every 64 values -> nb x 64 int16.  Values that would fall
  * beyond block nb-1 are dropped (the trailing pad symbols of loadEncodedData,

@@ -37,6 +37,8 @@ SIGNATURES = {
     "jpegamd_encode_image_rle_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
                                      _c.c_void_p],
+    "jpegamd_rle_encode_plane_noalloc_dev": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p,
+                                             _c.c_void_p],
     "jpegamd_rle_decode_plane_dev": [_c.c_void_p, _c.c_size_t, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                      _c.c_size_t, _c.c_void_p],
     "jpegamd_bin_encode": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
@@ -66,7 +68,8 @@ SIGNATURES = {
 }
 
 # the exported functions that do not return an int status (set up by hand in load())
-OTHER_RETURN_TYPES = ("jpegamd_last_error", "jpegamd_rle_workspace_bytes", "jpegamd_free", "jpegamd_context_destroy")
+OTHER_RETURN_TYPES = ("jpegamd_last_error", "jpegamd_rle_workspace_bytes", "jpegamd_rle_noalloc_max_blocks",
+                      "jpegamd_free", "jpegamd_context_destroy")
 
 _lib = None
 
@@ -96,6 +99,8 @@ def load():
             fn.restype = _c.c_int
         lib.jpegamd_rle_workspace_bytes.argtypes = [_c.c_size_t]
         lib.jpegamd_rle_workspace_bytes.restype = _c.c_size_t
+        lib.jpegamd_rle_noalloc_max_blocks.argtypes = []
+        lib.jpegamd_rle_noalloc_max_blocks.restype = _c.c_size_t
         lib.jpegamd_free.argtypes = [_c.c_void_p]
         lib.jpegamd_free.restype = None
         lib.jpegamd_context_destroy.argtypes = [_c.c_void_p]

@@ -39,6 +39,9 @@ template <class Body> int jpegamd_guarded(const char *what, Body body) noexcept
 // the copier's pinned buffers and streams for the current device, ahead of the first copy (jpegamd_init)
 __attribute__((visibility("hidden"))) int jpegamd_staged_copy_warm();
 
+// address of the no-alloc entry point's device scratch on the current device (rle_kernels.hip)
+__attribute__((visibility("hidden"))) int jpegamd_rle_noalloc_setup();
+
 // run-length stage of three planes whose per-block pair counts the encoder has written
 // (rle_kernels.hip); `sums` = one uint32 of device memory per 256 blocks of each plane
 __attribute__((visibility("hidden"))) int jpegamd_rle_encode_counted(

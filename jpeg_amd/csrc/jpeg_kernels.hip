@@ -626,6 +626,8 @@ int jpegamd_init(int device)
         return fail("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     // what the first host-pointer call would otherwise pay for (15 ms at 8192^2): the copier's
     // pinned staging buffers and streams
+    if (jpegamd_rle_noalloc_setup()) // this device's address of the no-alloc entry point's scratch
+        return 1;
     return jpegamd_staged_copy_warm();
 }
 

@@ -19,6 +19,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/jpeg_amd.h"
 #include "host_common.h"
@@ -430,6 +431,43 @@ int launch_rle_encode(const RlePlane *planes, int n_planes, uint32_t *sums, hipS
     return 0;
 }
 
+// ---- the entry point that allocates nothing (include/jpeg_amd.h) ------------------------
+// Its scratch (the per-workgroup pair counts that the three kernels hand to each other) is a
+// file-scope device array: every GPU the library runs on holds its own copy at its own
+// address for the life of the process.  `scratch` below is only the HOST-side handle of that
+// array -- never a device address: the address on the current device comes from
+// hipGetSymbolAddress, once per device, and that pointer is what the kernels are given.
+constexpr size_t kNoAllocMaxBlocks = (size_t)1 << 22; // 4 Mi blocks = a 16384 x 16384 luma plane
+constexpr size_t kNoAllocScratchWords = kNoAllocMaxBlocks / kBlocksPerWg + 64; // one uint32 per tile
+
+} // namespace
+
+static __device__ __align__(256) uint32_t scratch[kNoAllocScratchWords]; // 64.25 KiB per GPU
+
+namespace {
+
+std::mutex g_scratch_mu;
+uint32_t *g_scratch_ptr[kMaxDevices]; // device address of `scratch` on each device, once looked up
+
+int noalloc_scratch_for_current_device(uint32_t **out)
+{
+    int dev = -1;
+    JPEGAMD_HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices)
+        return jpegamd_fail("rle_encode_plane_noalloc: device %d beyond the %d this library keeps scratch for", dev,
+                            kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        JPEGAMD_HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p)
+            return jpegamd_fail("rle_encode_plane_noalloc: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = static_cast<uint32_t *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
 } // namespace
 
 int jpegamd_rle_encode_counted(int16_t *const coef[3], const size_t nb[3], const uint8_t *const counts[3],
@@ -445,6 +483,14 @@ int jpegamd_rle_encode_counted(int16_t *const coef[3], const size_t nb[3], const
     }
     return launch_rle_encode(pl, 3, sums, static_cast<hipStream_t>(stream));
 }
+
+// jpegamd_init(): look the scratch address up while set-up is going on, with the device current
+int jpegamd_rle_noalloc_setup()
+{
+    uint32_t *p = nullptr;
+    return noalloc_scratch_for_current_device(&p);
+}
+
 
 extern "C" {
 
@@ -494,6 +540,23 @@ int jpegamd_rle_encode_image_dev(const int16_t *const d_coef_zz[3], const size_t
         return jpegamd_fail("rle_encode_image: workspace of %zu bytes, need %zu (jpegamd_rle_workspace_bytes of the "
                             "three planes' blocks together)", workspace_bytes, jpegamd_rle_workspace_bytes(all));
     return launch_rle_encode(pl, 3, static_cast<uint32_t *>(d_workspace), static_cast<hipStream_t>(stream));
+}
+
+size_t jpegamd_rle_noalloc_max_blocks(void) { return kNoAllocMaxBlocks; }
+
+int jpegamd_rle_encode_plane_noalloc_dev(const int16_t *d_coef_zz, size_t nb, int32_t *d_pairs, size_t cap_pairs,
+                                         uint32_t *d_block_offsets, void *stream)
+{
+    if (check_rle_encode(d_coef_zz, nb, d_pairs, d_block_offsets, "rle_encode_plane_noalloc"))
+        return 1;
+    if (nb > kNoAllocMaxBlocks)
+        return jpegamd_fail("rle_encode_plane_noalloc: nb=%zu exceeds the built-in scratch (%zu blocks); use "
+                            "jpegamd_rle_encode_plane_dev with a workspace", nb, kNoAllocMaxBlocks);
+    uint32_t *work = nullptr;
+    if (noalloc_scratch_for_current_device(&work))
+        return 1;
+    const RlePlane pl{d_coef_zz, d_block_offsets, reinterpret_cast<int2 *>(d_pairs), cap_pairs, nullptr, (uint32_t)nb, 0};
+    return launch_rle_encode(&pl, 1, work, static_cast<hipStream_t>(stream));
 }
 
 int jpegamd_rle_decode_plane_dev(const int32_t *d_pairs, size_t n_pairs, size_t nb, int16_t *d_coef_zz,
