@@ -82,6 +82,13 @@ int jpegamd_encode_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t st
                              const int32_t q_luma[64], const int32_t q_chroma[64],
                              int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr,
                              void *stream);
+/* RGB2YCbCr (encode_decode.cpp:39-75) + chromaSubsampling (117-152) on their own: the colour
+ * stage of the fused encoder (the same kernel code, stopped before the transform) writing the
+ * planes main.cpp:99-104 holds at that point.  d_y: rows x cols bytes; d_cb, d_cr: rows/2 x
+ * cols/2 bytes, dense.  Bit-exact with the reference for every input triple (GPU test over all
+ * 2^24). */
+int jpegamd_colour_planes_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride, uint8_t *d_y, uint8_t *d_cb,
+                              uint8_t *d_cr, void *stream);
 /* The three decodeChannelGPU transforms (encode_decode.cpp:784-818) of mainDecode
  * (1365-1367) + upsampleChroma (154-173) + YCbCr2RGB (77-114) in ONE launch. */
 int jpegamd_decode_image_dev(const int16_t *d_coef_y, const int16_t *d_coef_cb,

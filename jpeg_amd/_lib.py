@@ -24,6 +24,8 @@ SIGNATURES = {
     "jpegamd_decode_plane_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p],
     "jpegamd_encode_image_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                  _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p],
+    "jpegamd_colour_planes_dev": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                  _c.c_void_p],
     "jpegamd_decode_image_dev": [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
                                  _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p],
     "jpegamd_encode_image": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,

@@ -95,6 +95,20 @@ def encode_image(bgr, q_luma, q_chroma, out=None, stream=None):
     return out
 
 
+def colour_planes(bgr, stream=None):
+    """RGB2YCbCr + chromaSubsampling (encode_decode.cpp:39-75, 117-152) through the fused
+    encoder's colour stage: cuda uint8 [rows, cols, 3] -> (Y [rows, cols], Cb, Cr [rows/2, cols/2])."""
+    import torch
+    rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
+    src = _dev(bgr, torch.uint8, "colour_planes")
+    y = torch.empty((rows, cols), dtype=torch.uint8, device=bgr.device)
+    cb = torch.empty((rows // 2, cols // 2), dtype=torch.uint8, device=bgr.device)
+    cr = torch.empty_like(cb)
+    _lib.check(_lib.load().jpegamd_colour_planes_dev(src, rows, cols, cols * 3, y.data_ptr(), cb.data_ptr(),
+                                                     cr.data_ptr(), _stream(stream)))
+    return y, cb, cr
+
+
 def decode_image(coef_y, coef_cb, coef_cr, rows, cols, q_luma, q_chroma, out=None, stream=None):
     """inverse of encode_image -> cuda uint8 [rows, cols, 3] (jpegamd_decode_image_dev)."""
     import torch

@@ -36,6 +36,9 @@ template <class Body> int jpegamd_guarded(const char *what, Body body) noexcept
 }
 #endif
 
+// compute units of the current device (jpeg_kernels.hip)
+__attribute__((visibility("hidden"))) int jpegamd_cu_count(int *out);
+
 // the copier's pinned buffers and streams for the current device, ahead of the first copy (jpegamd_init)
 __attribute__((visibility("hidden"))) int jpegamd_staged_copy_warm();
 

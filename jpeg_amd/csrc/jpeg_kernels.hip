@@ -46,7 +46,9 @@ namespace {
 struct CountPlanes {
     uint8_t *y, *cb, *cr; // one byte per block, raster order like the coefficient planes
 };
-template <bool kCounts>
+// kDump: stop after the colour stage and write the Y, Cb, Cr planes (RGB2YCbCr +
+// chromaSubsampling on their own: jpegamd_colour_planes_dev); `counts` then names the planes.
+template <bool kCounts, bool kDump>
 __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
     int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
@@ -61,14 +63,17 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
-    const int tile = blockIdx.x * kWavesPerWg + wave;
+    int tile = blockIdx.x * kWavesPerWg + wave;
     if (tile >= n_tiles)
         return; // whole wave leaves together; nothing else is shared between waves
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    // The grid is PERSISTENT when the host launches fewer waves than tiles: a wave then takes
+    // tiles tile, tile + tile_step, ... and fetches the first rows of its next tile while the
+    // current one is in its chroma round, so neither a workgroup launch nor a cold first fetch
+    // sits between two tiles.  Every wave leaves the loop when its next tile is beyond the image.
+    const int tile_step = gridDim.x * kWavesPerWg;
+    int tx = tile % tiles_x, ty = tile / tiles_x;
     uint8_t *stage = lds + wave * kWaveLds; // Y rows (8 x 512) alias the staging area
     uint8_t *cbuf = stage + kStageBytes;    // Cb: 8 x 256, Cr: 8 x 256
-
-    const int x0 = tx * kWaveTileW;
     const int bw_y = cols >> 3, bw_c = cols >> 4;
 
     // BGR rows are double-buffered in registers four tasks at a time: while the four tasks
@@ -77,28 +82,40 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     // slot is a fixed register; the buffers swap by moves once per four tasks, by which
     // time the loads issued four tasks earlier have landed.  Task T = 8*it + t covers
     // 2 rows x 4 pixels per lane: row pair rp = t>>1, pixel group g = lane + 64*(t&1).
-    // Loads are unconditional: lanes beyond the image edge re-read its last pixel group,
-    // tasks beyond 15 re-read tasks 14 and 15.
+    // Loads are unconditional: lanes beyond the image edge re-read its last pixel group;
+    // tasks 16..19 are tasks 0..3 of the wave's NEXT tile (or, without one, tasks 14 and 15 again).
     constexpr int kRing = 4;
     // The row base is uniform (scalar registers) and the lane's byte offset within a row
     // takes only two values, so a load costs no vector arithmetic: saddr + 32-bit voffset.
-    uint32_t lane_off[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        int x = x0 + 4 * (lane + 64 * h);
+    auto lane_offset = [&](int tile_x, int h) { // (separate scalars: arrays of them end up in scratch)
+        int x = tile_x * kWaveTileW + 4 * (lane + 64 * h);
         x = x < cols - 4 ? x : cols - 4;
-        lane_off[h] = 3u * (uint32_t)x;
-    }
+        return 3u * (uint32_t)x;
+    };
+    uint32_t lane_off0 = lane_offset(tx, 0), lane_off1 = lane_offset(tx, 1), next_off0 = 0, next_off1 = 0;
+    int next_ty = ty; // (set per tile below)
+    bool has_next = false;
     auto task_load = [&](int T, int odd, U3 &a, U3 &b) { // odd == T & 1, a compile-time constant at every call
-        T = T < 16 ? T : 14 + odd;
-        const uint8_t *rowp = bgr + (size_t)(ty * 16 + 2 * (T >> 1)) * stride;
-        a = *reinterpret_cast<const U3 *>(rowp + lane_off[odd]);
-        b = *reinterpret_cast<const U3 *>(rowp + stride + lane_off[odd]);
+        const bool ahead = T >= 16 && has_next;
+        const int row = ahead ? next_ty * 16 + 2 * ((T - 16) >> 1) : ty * 16 + 2 * ((T < 16 ? T : 14 + odd) >> 1);
+        const uint32_t off = odd ? (ahead ? next_off1 : lane_off1) : (ahead ? next_off0 : lane_off0);
+        const uint8_t *rowp = bgr + (size_t)row * stride;
+        a = *reinterpret_cast<const U3 *>(rowp + off);
+        b = *reinterpret_cast<const U3 *>(rowp + stride + off);
     };
     U3 ring_a[kRing], ring_b[kRing];
 #pragma unroll
     for (int i = 0; i < kRing; ++i)
         task_load(i, i & 1, ring_a[i], ring_b[i]);
+
+#pragma unroll 1
+    for (;;) {
+    const int x0 = tx * kWaveTileW;
+    const int next_tile = tile + tile_step;
+    has_next = next_tile < n_tiles;
+    const int next_tx = has_next ? next_tile % tiles_x : tx;
+    next_ty = has_next ? next_tile / tiles_x : ty;
+    next_off0 = lane_offset(next_tx, 0), next_off1 = lane_offset(next_tx, 1);
 
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
@@ -175,6 +192,27 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
             }
         }
         wave_lds_fence();
+        if constexpr (kDump) {
+            // the colour stage's planes as they stand in LDS: 8 Y rows now, the 8 chroma rows
+            // once both halves are through
+            if (it < 2) {
+                if (x0 + lane * 8 < cols)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        *reinterpret_cast<uint2 *>(counts.y + (size_t)(ty * 16 + it * 8 + r) * cols + x0 + lane * 8) =
+                            *reinterpret_cast<const uint2 *>(stage + r * 512 + lane * 8);
+                if (it == 1 && (x0 >> 1) + lane * 4 < (cols >> 1))
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const size_t o = (size_t)(ty * 8 + r) * (cols >> 1) + (x0 >> 1) + lane * 4;
+                        *reinterpret_cast<uint32_t *>(counts.cb + o) = *reinterpret_cast<const uint32_t *>(cbuf + r * 256 + lane * 4);
+                        *reinterpret_cast<uint32_t *>(counts.cr + o) =
+                            *reinterpret_cast<const uint32_t *>(cbuf + 2048 + r * 256 + lane * 4);
+                    }
+                wave_lds_fence();
+            }
+            continue;
+        }
 
         // ---- transform: lane = block ---------------------------------------
         const bool luma = it < 2;
@@ -255,6 +293,11 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
         }
         wave_lds_fence(); // staging area is free again
     }
+    if (!has_next)
+        break;
+    tile = next_tile, tx = next_tx, ty = next_ty;
+    lane_off0 = next_off0, lane_off1 = next_off1;
+    } // tiles of this wave
 }
 
 // ------------------------------------------------------------- fused decoder
@@ -582,6 +625,13 @@ Transform transform_choice()
     return Transform::valu;
 }
 
+// JPEGAMD_GRID=pertile: one wave per tile (round 1); default: persistent waves (see the kernel)
+bool encoder_grid_persistent()
+{
+    const char *e = getenv("JPEGAMD_GRID");
+    return !(e && strcmp(e, "pertile") == 0);
+}
+
 struct DevBuf { // host-pointer entry points: per-call device memory
     void *p = nullptr;
     ~DevBuf()
@@ -594,6 +644,24 @@ struct DevBuf { // host-pointer entry points: per-call device memory
 } // namespace
 
 static thread_local char g_err[512] = "";
+
+// compute units of the current device (cached per device)
+int jpegamd_cu_count(int *out)
+{
+    static int cached[64];
+    int dev = -1;
+    JPEGAMD_HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64)
+        return jpegamd_fail("device %d beyond the 64 this library knows", dev);
+    int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (!n) {
+        JPEGAMD_HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        n = n > 0 ? n : 1;
+        __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+    }
+    *out = n;
+    return 0;
+}
 
 int jpegamd_fail(const char *fmt, ...)
 {
@@ -646,11 +714,17 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
         return fail("encode_image: null coefficient pointer");
     const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
     const int n_tiles = tiles_x * (rows / 16);
-    const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    if (encoder_grid_persistent()) { // no more workgroups than are resident at once: 3 per CU (LDS)
+        int cus = 0;
+        if (jpegamd_cu_count(&cus))
+            return 1;
+        grid = grid < 3 * cus ? grid : 3 * cus;
+    }
     if (counts) {
-        hipExtLaunchKernelGGL(encode_image_kernel<true>, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream,
-                              start, stop, 0, d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x,
-                              n_tiles, *counts);
+        const auto kern = &encode_image_kernel<true, false>;
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop, 0, d_bgr, rows, cols,
+                              stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles, *counts);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -658,8 +732,9 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
     if (tr != Transform::valu)
         return jpegamd_launch_encode_variant(tr == Transform::mfma_f32 ? 1 : 2, grid, stream, start, stop, d_bgr, rows,
                                              cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
-    hipExtLaunchKernelGGL(encode_image_kernel<false>, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start,
-                          stop, 0, d_bgr, rows, cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles,
+    const auto kern = &encode_image_kernel<false, false>;
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop, 0, d_bgr, rows, cols,
+                          stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles,
                           CountPlanes{nullptr, nullptr, nullptr});
     HIPCHK(hipGetLastError());
     return 0;
@@ -690,6 +765,26 @@ int jpegamd_encode_image_dev(const uint8_t *d_bgr, int rows, int cols, size_t st
 {
     return launch_encode_image(d_bgr, rows, cols, stride, q_luma, q_chroma, d_coef_y, d_coef_cb, d_coef_cr, stream,
                                nullptr, nullptr);
+}
+
+int jpegamd_colour_planes_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride, uint8_t *d_y, uint8_t *d_cb,
+                              uint8_t *d_cr, void *stream)
+{
+    if (check_image(d_bgr, rows, cols, stride, "colour_planes"))
+        return 1;
+    if (!d_y || !d_cb || !d_cr || (reinterpret_cast<uintptr_t>(d_y) & 7) || (reinterpret_cast<uintptr_t>(d_cb) & 3) ||
+        (reinterpret_cast<uintptr_t>(d_cr) & 3))
+        return fail("colour_planes: null plane pointer, or Y not 8-byte / Cb, Cr not 4-byte aligned");
+    QuantPair qp{}; // (the transform is not reached)
+    const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
+    const int n_tiles = tiles_x * (rows / 16);
+    const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    const auto kern = &encode_image_kernel<false, true>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, d_bgr, rows, cols, stride, qp,
+                       (int16_t *)nullptr, (int16_t *)nullptr, (int16_t *)nullptr, tiles_x, n_tiles,
+                       CountPlanes{d_y, d_cb, d_cr});
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 int jpegamd_encode_image_rle_dev(const uint8_t *d_bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],

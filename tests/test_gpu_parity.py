@@ -131,13 +131,15 @@ def test_image_vs_oracle(gpu, orc, model, kind, seed, rows, cols, qf):
         assert (coefs[1] == 0).all() and (coefs[2] == 0).all()
 
 
-def test_image_of_exact_ties_only(gpu, orc, model):
+@pytest.mark.parametrize("grid", ["persistent", "pertile"])
+def test_image_of_exact_ties_only(gpu, orc, model, monkeypatch, grid):
     """Every pixel an exact x.5 tie of the forward colour transform (all 16 782 Y ties and
     Cb and Cr ties of both directions, the two 256 -> 0 wraps among them): the encoder's
     re-evaluation path runs for every lane of every test, in both rows, and the result must
     still be the oracle's colour planes through the model transform, bit for bit (QF = 100:
     a wrong colour byte changes coefficients)."""
     import jpeg_amd
+    monkeypatch.setenv("JPEGAMD_GRID", grid)
     v = np.arange(256, dtype=np.int64)
     p0, p1, p2 = np.meshgrid(v, v, v, indexing="ij")
     ties = ((299 * p0 + 587 * p1 + 114 * p2) % 1000 == 500) | ((p0 == p1) & ((p2 - p0) % 2 == 1)) \
@@ -155,6 +157,42 @@ def test_image_of_exact_ties_only(gpu, orc, model):
         assert np.array_equal(g, m)
     for g, w, n in zip(coefs, orc.encode_image(bgr, qy, qc), "Y Cb Cr".split()):
         _check_coef(g, w, f"ties {n}")
+
+
+@pytest.mark.parametrize("grid", ["persistent", "pertile"])
+def test_colour_stage_on_all_2_24_triples(gpu, orc, monkeypatch, grid):
+    """VERDICT r1 4(a) / SURVEY 4(iii): the encoder's colour stage ON THE DEVICE, seen directly
+    (jpegamd_colour_planes_dev = the fused encoder's kernel stopped before the transform), over
+    a 4096^2 image that holds every one of the 2^24 (B, G, R) triples once: Y, and the
+    truncating quad means of Cb and Cr, must equal RGB2YCbCr + chromaSubsampling
+    (encode_decode.cpp:39-75, 117-152) bit for bit -- exact ties, the two 256 -> 0 wraps and the
+    device-side branches of jpeg_math.h included.  Two arrangements: triples in counting order
+    (neighbours differ in one channel: long runs of ties in a wave) and shuffled (every quad mixes
+    unrelated triples)."""
+    import torch
+    import jpeg_amd
+    monkeypatch.setenv("JPEGAMD_GRID", grid)  # persistent waves (default) / one wave per tile
+    n = 1 << 24
+    idx = np.arange(n, dtype=np.uint32)
+    for name, order in (("counting", idx), ("shuffled", np.random.default_rng(24).permutation(idx))):
+        bgr = np.empty((4096, 4096, 3), np.uint8)
+        flat = bgr.reshape(-1, 3)
+        flat[:, 0], flat[:, 1], flat[:, 2] = order & 255, (order >> 8) & 255, order >> 16
+        y, cb, cr = (t.cpu().numpy() for t in jpeg_amd.colour_planes(_t(bgr, gpu)))
+        wy, wcb, wcr = orc.chroma_subsample(orc.rgb2ycbcr(bgr))
+        assert np.array_equal(y, wy), f"{name}: {(y != wy).sum()} luma bytes differ"
+        assert np.array_equal(cb, wcb), f"{name}: {(cb != wcb).sum()} Cb means differ"
+        assert np.array_equal(cr, wcr), f"{name}: {(cr != wcr).sum()} Cr means differ"
+    # the quad means alone could hide a +-1 on one Cb/Cr byte (truncation): every triple also as a
+    # uniform 2x2 quad, where the mean IS the byte -- 8192 x 8192 pixels, checked in four bands
+    quad = np.repeat(np.repeat(idx.reshape(4096, 4096), 2, axis=0), 2, axis=1)
+    for band in range(4):
+        q = quad[band * 2048:(band + 1) * 2048]
+        bgr = np.ascontiguousarray(np.stack([q & 255, (q >> 8) & 255, q >> 16], -1).astype(np.uint8))
+        y, cb, cr = (t.cpu().numpy() for t in jpeg_amd.colour_planes(_t(bgr, gpu)))
+        ycc = orc.rgb2ycbcr(bgr)
+        assert np.array_equal(y, ycc[:, :, 0])
+        assert np.array_equal(cb, ycc[::2, ::2, 1]) and np.array_equal(cr, ycc[::2, ::2, 2]), band
 
 
 def test_fused_decoder_colour_stage_is_bit_exact_on_its_own_planes(gpu, orc):
