@@ -25,13 +25,29 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_PIXEL_ENC = 6.0  # 3 B BGR read + 1.5 coefficients x 2 B written
 BYTES_PER_PIXEL_DEC = 6.0  # 3 B coefficients read + 3 B BGR written
-# HBM bytes per launch at 8192^2 QF=50 from rocprofv3 PMC passes (separate --pmc runs of
-# tools/prof_run.py, profiles/r01_h_pmc_hbm_traffic.txt): FETCH_SIZE x 2 (the gfx950
-# correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both reported in KiB.
-MEASURED_TRAFFIC = {
-    (8192, 8192, 50): {"encode_image_kernel": (100236 * 2 + 196608) * 1024,
-                       "decode_image_kernel": (98544 * 2 + 196649) * 1024},
-}
+# HBM bytes per launch from rocprofv3 PMC passes over the tree as shipped (tools/gpu_pmc_hbm.sh:
+# separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/prof_run.py; FETCH_SIZE x 2, the gfx950
+# correction of MI355X_MICROARCH.md's HBM section, + WRITE_SIZE, both counted in KiB).  The script
+# writes the file below; bench.py only reads it, and reports null when it has no entry.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+
+
+def measured_traffic(rows, cols, quality, kernel):
+    try:
+        table = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None
+    return table.get(f"{rows}x{cols}_qf{quality}", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(bgr_crop, qy, qc):
@@ -49,7 +65,10 @@ def cpu_baseline(bgr_crop, qy, qc):
     qy = np.ascontiguousarray(qy, np.int32)
     qc = np.ascontiguousarray(qc, np.int32)
     res = {}
-    for name, flavour, threads in (("cpu_1t", 0, 1), ("omp_all", 1, min(16, lib.orc_max_threads()))):
+    # flavour 0 = the reference's CPU path (encodeChannel / decodeChannel), 1 = its OMP path's separable
+    # arithmetic (encode_decode.cpp:849-1035) at the reference's hard-coded omp_set_num_threads(2)
+    # (:908, :1018) and on all the box's cores
+    for name, flavour, threads in (("cpu_1t", 0, 1), ("omp_2t", 1, 2), ("omp_all", 1, min(16, lib.orc_max_threads()))):
         t0 = time.perf_counter()
         assert lib.orc_encode_image(p(bgr_crop), r, c, p(qy), p(qc), flavour, threads, p(cy), p(cb), p(cr), None) == 0
         assert lib.orc_decode_image(p(cy), p(cb), p(cr), r, c, p(qy), p(qc), flavour, threads, p(out)) == 0
@@ -281,7 +300,7 @@ def main():
                        + (", REHEARSAL: ranks share one GPU" if shared else "")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": MEASURED_TRAFFIC.get((rows, cols, args.quality), {}).get(dominant),
+                         "traffic": measured_traffic(rows, cols, args.quality, dominant),
                          "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_ENC * npix,
                          "encode_ms": enc_ms, "decode_ms": dec_ms,
                          "encode_GBs": enc_gbs, "decode_GBs": dec_gbs,
@@ -300,6 +319,10 @@ def main():
             base = cpu_baseline(host, qy, qc)
             line["cpu_baseline"] = {
                 "value": base["cpu_1t"]["mpix_s"], "unit": "Mpixel/s", "cores": 1, "kind": "port",
+                "cpu_model": cpu_model(), "host_cores_visible": os.cpu_count(),
+                "omp_reference_2_threads": {"value": base["omp_2t"]["mpix_s"], "cores": 2,
+                                            "note": "the reference's OMP path runs at omp_set_num_threads(2), "
+                                                    "encode_decode.cpp:908, 1018"},
                 "sample": f"top-left {crop_r}x{crop_c} of the same image, one encode+decode pass, oracle single thread "
                           f"({base['cpu_1t']['seconds']:.1f} s)",
                 "omp_flavour": {"value": base["omp_all"]["mpix_s"], "cores": base["omp_all"]["threads"],

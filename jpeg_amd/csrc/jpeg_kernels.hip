@@ -337,13 +337,15 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
-    const int tile = blockIdx.x * kWavesPerWg + wave;
+    int tile = blockIdx.x * kWavesPerWg + wave;
     if (tile >= n_tiles)
         return;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    // persistent like the encoder: a wave takes tiles tile, tile + tile_step, ... and fetches the
+    // chroma coefficients of its next tile during the current one's last luma round
+    const int tile_step = gridDim.x * kWavesPerWg;
+    int tx = tile % tiles_x, ty = tile / tiles_x;
     uint8_t *stage = lds + wave * kWaveLds;
     uint8_t *cbuf = stage + kStageBytes;
-    const int x0 = tx * kWaveTileW;
     const int bw_y = cols >> 3, bw_c = cols >> 4;
 
     // Coefficients of round `r` (r = 0: the tile's 32 Cb + 32 Cr blocks; r = 1, 2: its two
@@ -359,6 +361,12 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     fetch_coefs(0, coef_y, coef_cb, coef_cr, tx, ty, bw_y, bw_c, lane, pre);
 
 #pragma unroll 1
+    for (;;) {
+    const int x0 = tx * kWaveTileW;
+    const int next_tile = tile + tile_step;
+    const bool has_next = next_tile < n_tiles;
+    const int next_tx = has_next ? next_tile % tiles_x : tx, next_ty = has_next ? next_tile / tiles_x : ty;
+#pragma unroll 1
     for (int it = 0; it < 3; ++it) {
         const bool luma = it > 0;
         // ---- staged coefficients: 64 blocks x 128 B at a 144 B pitch -----------
@@ -370,6 +378,8 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
         }
         if (it < 2)
             fetch_coefs(it + 1, coef_y, coef_cb, coef_cr, tx, ty, bw_y, bw_c, lane, pre);
+        else if (has_next)
+            fetch_coefs(0, coef_y, coef_cb, coef_cr, next_tx, next_ty, bw_y, bw_c, lane, pre);
         wave_lds_fence();
 
         // ---- transform: lane = block ---------------------------------------
@@ -426,6 +436,10 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
             wave_lds_fence(); // Y rows consumed before the next round stages over them
         }
     }
+    if (!has_next)
+        break;
+    tile = next_tile, tx = next_tx, ty = next_ty;
+    } // tiles of this wave
 }
 
 // --------------------------------------------------------------- plane level
@@ -625,7 +639,7 @@ Transform transform_choice()
     return Transform::valu;
 }
 
-// JPEGAMD_GRID=pertile: one wave per tile (round 1); default: persistent waves (see the kernel)
+// JPEGAMD_GRID=pertile: one wave per tile (round 1); default: persistent waves (both fused kernels)
 bool encoder_grid_persistent()
 {
     const char *e = getenv("JPEGAMD_GRID");
@@ -752,7 +766,13 @@ static int launch_decode_image(const int16_t *d_coef_y, const int16_t *d_coef_cb
         return fail("decode_image: null coefficient pointer");
     const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
     const int n_tiles = tiles_x * (rows / 16);
-    const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    if (encoder_grid_persistent()) { // no more workgroups than are resident at once: 3 per CU (LDS)
+        int cus = 0;
+        if (jpegamd_cu_count(&cus))
+            return 1;
+        grid = grid < 3 * cus ? grid : 3 * cus;
+    }
     hipExtLaunchKernelGGL(decode_image_kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop,
                           0, d_coef_y, d_coef_cb, d_coef_cr, rows, cols, qp, d_bgr, stride, tiles_x, n_tiles);
     HIPCHK(hipGetLastError());

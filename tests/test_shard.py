@@ -103,6 +103,71 @@ def test_gloo_world3_with_an_empty_rank(tmp_path):
     assert result.read_text() == "ok"
 
 
+def _bin_worker(rank, world, port, case, result_path):
+    """every rank encodes its strip (oracle as the stand-in for the GPU), the encoded strips go to
+    the writer, the writer's .bin must be the single-rank file byte for byte"""
+    sys.path.insert(0, HERE)
+    import hashlib
+    import torch.distributed as dist
+    import oracle_lib
+    import jpeg_amd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.Oracle()
+        qy, qc = orc.quality_tables(50)
+        if case == "lena":
+            from PIL import Image
+            rgb = np.array(Image.open(os.path.join(HERE, "golden", "lena_color_1024.png")).convert("RGB"))
+            img = np.ascontiguousarray(rgb[:, :, ::-1])
+        else:
+            rows, cols = case
+            img = synth_image(rows, cols, 9, "photo").numpy()
+        rows, cols = img.shape[:2]
+        r0, r1 = shard.strip_rows(rows, world, rank)
+
+        def encode_strip(strip):
+            coefs = orc.encode_image(strip.numpy(), qy, qc, threads=2)
+            return [torch.from_numpy(orc.rle_stream(c).reshape(-1, 2).copy()) for c in coefs]
+
+        writer = world - 1 if case != "lena" else 0    # the writer need not be rank 0
+        data = shard.compress_image_sharded(torch.from_numpy(img[r0:r1].copy()), rows, cols, qy, qc,
+                                            writer=writer, encode_strip=encode_strip)
+        assert (data is None) == (rank != writer)
+        if rank == writer:
+            whole = orc.write_bin(*(orc.rle_stream(c) for c in orc.encode_image(img, qy, qc, threads=2)), rows, cols)
+            ok = data == whole
+            if case == "lena":
+                gold = open(os.path.join(HERE, "golden", "compressed_image_cpu_50.bin"), "rb").read()
+                ok = ok and data == gold and hashlib.sha256(data).hexdigest().startswith("7870d3fec500635c")
+            # and back: the writer decodes the container, the strips of the planes go out again
+            dims, syms = jpeg_amd.bin_decode(data)
+            nbs = ((rows // 8) * (cols // 8), (rows // 16) * (cols // 16), (rows // 16) * (cols // 16))
+            planes = [torch.from_numpy(orc.decode_rle(s, nb)[0]) for s, nb in zip(syms, nbs)]
+        else:
+            planes = None
+        strip = shard.scatter_planes_from_writer(planes, rows, cols, writer=writer)
+        want = orc.encode_image(img[r0:r1], qy, qc, threads=2) if r1 > r0 else [np.zeros((0, 64), np.int16)] * 3
+        back = all(np.array_equal(s.numpy(), w) for s, w in zip(strip, want))
+        flag = torch.tensor([1 if back else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == writer:
+            with open(result_path, "w") as f:
+                f.write("ok" if ok and int(flag) == 1 else f"mismatch bin={ok} planes={int(flag)}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, (96, 160)), (3, (32, 64)), (2, "lena"), (3, "lena")])
+def test_gloo_encoded_strips_to_the_writer_give_the_single_rank_bin(tmp_path, world, case):
+    """N ranks, ONE .bin, byte-identical to the single-rank file (and, for the
+    reference's Lena, to its committed golden); world 3 on a 32-row image has an empty rank."""
+    import torch.multiprocessing as mp
+    result = tmp_path / "result.txt"
+    mp.spawn(_bin_worker, args=(world, _free_port(), case, str(result)), nprocs=world, join=True)
+    assert result.read_text() == "ok"
+
+
 @pytest.mark.gpu
 def test_virtual_ranks_on_one_gpu_equal_whole_image(gpu):
     """G strips encoded independently by the kernels concatenate to the whole-image
@@ -123,3 +188,24 @@ def test_virtual_ranks_on_one_gpu_equal_whole_image(gpu):
             assert torch.equal(strip, rec[r0:r1])
         for k in range(3):
             assert torch.equal(torch.cat([p[k] for p in parts]), whole[k])
+
+
+@pytest.mark.gpu
+def test_virtual_ranks_encoded_strips_give_the_single_gpu_bin(gpu):
+    """the strips' (value, run) streams from the real kernels (jpegamd_encode_image_rle_dev per
+    strip), concatenated in rank order and entropy-coded on the device, are the .bin of the
+    whole image through jpegamd_compress_image"""
+    import jpeg_amd
+    rows, cols = 528, 1040
+    qy, qc = jpeg_amd.quality_tables(50)
+    img = synth_image(rows, cols, 13, "photo", device=gpu)
+    want = jpeg_amd.compress_image(img.cpu().numpy(), qy, qc)
+    for world in (1, 2, 5, 40):  # 33 MCU rows: 40 ranks leave some without a strip
+        streams = [[], [], []]
+        for g in range(world):
+            r0, r1 = shard.strip_rows(rows, world, g)
+            if r1 > r0:
+                for k, (pairs, _) in enumerate(jpeg_amd.encode_image_rle(img[r0:r1].contiguous(), qy, qc)[1]):
+                    streams[k].append(pairs)
+        data = jpeg_amd.bin_encode_dev(*(torch.cat(s) for s in streams), rows, cols)
+        assert data == want, world
