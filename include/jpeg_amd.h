@@ -219,6 +219,10 @@ int jpegamd_context_decompress_image(jpegamd_context *ctx, const uint8_t *bin, s
  * (row-major 8x8, clamped to 1..255); non-zero for a quality outside that range. */
 int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]);
 
+/* analysis.cpp:43-90: the two FIXED table pairs analysis uses instead of scaling (quality >= 90:
+ * its own pair, the luma one with 12 at [5][5]; otherwise the base tables). */
+int jpegamd_analysis_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]);
+
 /* Times `iters` steps of encode followed by decode on `stream`, in that alternating
  * sequence, with HIP events recorded on that same stream between every two launches;
  * writes the mean milliseconds per launch of each kernel.  Used by bench.py for the

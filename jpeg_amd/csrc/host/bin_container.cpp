@@ -18,6 +18,7 @@
 // std::string (:458-466), codes live in flat tables indexed by symbol and bits are
 // packed MSB-first as they are produced (:1093-1127 give the byte layout).
 #include <algorithm>
+#include <exception>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -141,25 +142,40 @@ unsigned plane_threads(size_t n)
     return (unsigned)std::min<size_t>(std::min<size_t>(want, hw), 16);
 }
 
-template <class F> void parallel_chunks(unsigned nt, F f) // f(chunk index)
+// f(chunk index) on nt threads.  The lambdas allocate (vectors, the window table): an exception
+// in a worker must not reach std::terminate, and one on the calling thread must not leave
+// joinable threads behind -- every chunk's exception is caught where it happens, all threads are
+// joined, and the first one is rethrown on the caller (jpegamd_guarded turns it into a status).
+template <class F> void parallel_chunks(unsigned nt, F f)
 {
     if (nt <= 1) {
         f(0u);
         return;
     }
+    std::vector<std::exception_ptr> err(nt);
+    auto guarded = [&](unsigned i) {
+        try {
+            f(i);
+        } catch (...) {
+            err[i] = std::current_exception();
+        }
+    };
     std::vector<std::thread> th;
-    th.reserve(nt - 1);
     unsigned started = 1;
     try {
+        th.reserve(nt - 1);
         for (; started < nt; ++started)
-            th.emplace_back(f, started);
-    } catch (const std::system_error &) { // no more threads to be had: the rest runs here
+            th.emplace_back(guarded, started);
+    } catch (...) { // no more threads (or memory for them) to be had: the rest runs here
     }
-    f(0u);
+    guarded(0u);
     for (unsigned i = started; i < nt; ++i)
-        f(i);
+        guarded(i);
     for (auto &t : th)
         t.join();
+    for (auto &e : err)
+        if (e)
+            std::rethrow_exception(e);
 }
 
 // ---------------------------------------------------------------- plane decoder

@@ -196,6 +196,31 @@ int jpegamd_quality_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64]
     return 0;
 }
 
+int jpegamd_analysis_tables(int quality, int32_t q_luma[64], int32_t q_chroma[64])
+{
+    // analysis.cpp:43-90, literally: no scaling, a fixed pair for quality >= 90 (whose luma table has
+    // 12 at [5][5] where the scaled table would have 21, and whose chroma table is not the Annex-K one)
+    // and the base pair otherwise
+    static const uint8_t hi_luma[64] = {3,  2,  2,  3,  5,  8,  10, 12, 2,  2,  3,  4,  5,  12, 12, 11,
+                                        3,  3,  3,  5,  8,  11, 14, 11, 3,  3,  4,  6,  10, 17, 16, 12,
+                                        4,  4,  7,  11, 14, 22, 21, 15, 5,  7,  11, 13, 16, 12, 23, 18,
+                                        10, 13, 16, 17, 21, 24, 24, 21, 14, 18, 19, 20, 22, 20, 20, 20};
+    static const uint8_t hi_chroma[64] = {11, 12, 14, 19, 26, 58, 60, 55, 12, 18, 21, 28, 32, 57, 59, 56,
+                                          14, 21, 25, 30, 59, 59, 59, 59, 19, 28, 30, 59, 59, 59, 59, 59,
+                                          26, 32, 59, 59, 59, 59, 59, 59, 58, 57, 59, 59, 59, 59, 59, 59,
+                                          60, 59, 59, 59, 59, 59, 59, 59, 55, 56, 59, 59, 59, 59, 59, 59};
+    if (!q_luma || !q_chroma)
+        return jpegamd_fail("analysis_tables: null pointer");
+    if (quality < 1 || quality > 100)
+        return jpegamd_fail("Quality must be between 1 and 100");
+    if (quality >= 90) {
+        for (int i = 0; i < 64; ++i)
+            q_luma[i] = hi_luma[i], q_chroma[i] = hi_chroma[i];
+        return 0;
+    }
+    return jpegamd_quality_tables(50, q_luma, q_chroma); // scale factor 100: the base tables themselves
+}
+
 static int bin_encode_dev_impl(const int32_t *d_sym_y, size_t n_y, const int32_t *d_sym_cb, size_t n_cb,
                            const int32_t *d_sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
                            uint8_t *out, size_t cap, size_t *out_len)

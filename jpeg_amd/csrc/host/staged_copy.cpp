@@ -87,13 +87,14 @@ private:
     {
         if (device_ == device)
             return 0;
+        device_ = -1; // until everything below has succeeded the copier belongs to no device
         for (int t = 0; t < kThreads; ++t) { // first use, or another device: (re)create streams and events
-            if (stream_[t]) {
+            if (stream_[t])
                 (void)hipStreamDestroy(stream_[t]);
-                (void)hipEventDestroy(done_[t][0]);
-                (void)hipEventDestroy(done_[t][1]);
-                stream_[t] = nullptr;
-            }
+            for (int b = 0; b < 2; ++b)
+                if (done_[t][b])
+                    (void)hipEventDestroy(done_[t][b]);
+            stream_[t] = nullptr, done_[t][0] = done_[t][1] = nullptr;
             for (int b = 0; b < 2; ++b)
                 if (!pin_[t][b])
                     JPEGAMD_HIPCHK(hipHostMalloc(&pin_[t][b], kChunk, hipHostMallocPortable));

@@ -919,14 +919,17 @@ int jpegamd_fdct_quant_blocks(const int32_t *blocks, size_t nb, const int32_t q[
         return 0;
     if (!blocks || !out)
         return fail("fdct_quant_blocks: null pointer");
+    // device memory per call, like kernel.cu:97-104 / 160-164 (no state survives the call); the
+    // copies go through the staged copier (pinned buffers on worker threads: ~10x a pageable hipMemcpy)
     DevBuf in, res;
     HIPCHK(hipMalloc(&in.p, nb * 64 * sizeof(int32_t)));
     HIPCHK(hipMalloc(&res.p, nb * 64 * sizeof(float)));
-    HIPCHK(hipMemcpy(in.p, blocks, nb * 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (jpegamd_staged_copy_linear(in.p, const_cast<int32_t *>(blocks), nb * 64 * sizeof(int32_t), true))
+        return 1;
     if (jpegamd_fdct_quant_blocks_dev((const int32_t *)in.p, nb, q, (float *)res.p, nullptr))
         return 1;
-    HIPCHK(hipMemcpy(out, res.p, nb * 64 * sizeof(float), hipMemcpyDeviceToHost));
-    return 0;
+    HIPCHK(hipDeviceSynchronize()); // the kernel ran on the null stream, the copier uses its own
+    return jpegamd_staged_copy_linear(res.p, out, nb * 64 * sizeof(float), false);
 }
 
 int jpegamd_dequant_idct_blocks(const float *coef, size_t nb, const int32_t q[64], int32_t *out)
@@ -938,11 +941,12 @@ int jpegamd_dequant_idct_blocks(const float *coef, size_t nb, const int32_t q[64
     DevBuf in, res;
     HIPCHK(hipMalloc(&in.p, nb * 64 * sizeof(float)));
     HIPCHK(hipMalloc(&res.p, nb * 64 * sizeof(int32_t)));
-    HIPCHK(hipMemcpy(in.p, coef, nb * 64 * sizeof(float), hipMemcpyHostToDevice));
+    if (jpegamd_staged_copy_linear(in.p, const_cast<float *>(coef), nb * 64 * sizeof(float), true))
+        return 1;
     if (jpegamd_dequant_idct_blocks_dev((const float *)in.p, nb, q, (int32_t *)res.p, nullptr))
         return 1;
-    HIPCHK(hipMemcpy(out, res.p, nb * 64 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    return 0;
+    HIPCHK(hipDeviceSynchronize());
+    return jpegamd_staged_copy_linear(res.p, out, nb * 64 * sizeof(int32_t), false);
 }
 
 int jpegamd_encode_image(const uint8_t *bgr, int rows, int cols, size_t stride,

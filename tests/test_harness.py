@@ -136,3 +136,67 @@ def test_harness_other_quality_and_output_dir(gpu, tmp_path):
     assert data == jpeg_amd.compress_image(img, *jpeg_amd.quality_tables(90))
     r = _run(["-o", "missing_dir"], "a.ppm\n", tmp_path)
     assert r.returncode == 1 and "Cannot open file for writing" in r.stderr
+
+
+# ---- jpegamd_analysis: the GPU leg of analysis.cpp (13 numbers, fixed table pairs) -------------
+ANALYSIS = os.path.join(ROOT, "jpeg_amd", "jpegamd_analysis")
+
+
+def test_analysis_tables_are_the_literal_pairs_of_analysis_cpp(orc):
+    """analysis.cpp:43-90: no scaling; quality >= 90 selects its own pair (luma [5][5] == 12),
+    anything else the base pair.  C ABI == Python table == oracle restatement."""
+    import jpeg_amd
+    from jpeg_amd import _lib
+    lib = _lib.load()
+    for q in (1, 10, 49, 50, 89, 90, 95, 100):
+        a, b = np.zeros(64, np.int32), np.zeros(64, np.int32)
+        assert lib.jpegamd_analysis_tables(q, a.ctypes.data, b.ctypes.data) == 0
+        py, pc = jpeg_amd.analysis_tables(q)
+        oy, oc = orc.analysis_tables(q)
+        assert np.array_equal(a, py) and np.array_equal(b, pc) and np.array_equal(a, oy) and np.array_equal(b, oc)
+        if q >= 90:
+            assert a[5 * 8 + 5] == 12 and b[0] == 11
+        else:
+            assert np.array_equal(a, jpeg_amd.quality_tables(50)[0])
+    a = np.zeros(64, np.int32)
+    assert lib.jpegamd_analysis_tables(0, a.ctypes.data, a.ctypes.data) != 0
+
+
+def test_analysis_usage_errors(tmp_path):
+    r = subprocess.run([ANALYSIS], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert r.returncode == 1 and "Usage:" in r.stderr and "<image_path> [quality]" in r.stderr   # analysis.cpp:35
+    r = subprocess.run([ANALYSIS, "x.png", "101"], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert r.returncode == 1 and "Invalid quality argument: Quality must be between 1 and 100" in r.stderr
+    r = subprocess.run([ANALYSIS, "no_such.png"], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert r.returncode == 1 and "Could not open or find the image" in r.stderr
+
+
+@pytest.mark.gpu
+def test_analysis_prints_thirteen_numbers_in_the_reference_positions(gpu, lena_bgr, tmp_path):
+    """parsed exactly as metric_image_file.py:41-65 does (non-empty lines, float of the text after
+    the last ':').  At quality 50 analysis.cpp's tables are main.cpp's, so the file is the golden."""
+    import shutil
+    shutil.copy(os.path.join(GOLD, "lena_color_1024.png"), tmp_path / "lena.png")
+    os.mkdir(tmp_path / "output")
+    r = subprocess.run([ANALYSIS, "lena.png", "50", "--cpu-encode-ms", "2993", "--cpu-decode-ms", "3236"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=110)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 13
+    v = [float(ln.split(":")[-1].strip()) for ln in lines]
+    data = (tmp_path / "output" / "compressed_image_gpu.bin").read_bytes()
+    assert hashlib.sha256(data).hexdigest() == "7870d3fec500635c7ef9dc5a98f985f31dbb2c91b0beb8d0c6ba9f9dbf82b2bf"
+    assert v[0] > 1 and v[1] > 1                                   # gains against the given CPU times
+    assert abs(v[5] - 3145728 / len(data)) < 1e-2                   # ratio GPU (csv: 23.96 for the 1024^2 Lena)
+    assert abs(v[9] - 19.4944) < 0.05 and abs(v[10] - 35.2317) < 0.01   # MSE / PSNR GPU vs BASELINE.md's CPU values
+    for i in (2, 3, 4, 6, 7, 8, 11, 12):                            # CPU / OMP slots: no such back-end here
+        assert v[i] != v[i]
+    assert (tmp_path / "output" / "decompress_image_gpu.png").exists()
+    # quality >= 90 switches to the other fixed pair
+    r = subprocess.run([ANALYSIS, "lena.png", "95"], capture_output=True, text=True, cwd=tmp_path, timeout=110)
+    assert r.returncode == 0, r.stderr
+    hi = [float(ln.split(":")[-1].strip()) for ln in r.stdout.splitlines() if ln.strip()]
+    assert hi[5] < v[5] and hi[10] > v[10] and hi[0] != hi[0]
+    import jpeg_amd
+    assert (tmp_path / "output" / "compressed_image_gpu.bin").read_bytes() == \
+        jpeg_amd.compress_image(lena_bgr, *jpeg_amd.analysis_tables(95))
