@@ -70,11 +70,22 @@ def _stream(stream):
     return ctypes.c_void_p(int(stream))
 
 
-def _dev(t, dtype, what):
+def _dev(t, dtype, what, numel=None):
+    """device pointer of a contiguous cuda tensor of `dtype` (and exactly `numel` elements: the
+    C ABI takes bare pointers, a wrong size would be an out-of-bounds access, not an error)"""
     import torch
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise TypeError(f"{what}: expected a contiguous {dtype} tensor on the GPU")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{what}: {t.numel()} elements, expected {numel}")
     return t.data_ptr()
+
+
+def _plane_sizes(rows, cols):
+    if rows <= 0 or cols <= 0 or rows % 16 or cols % 16:
+        raise _lib.JpegAmdError(f"rows={rows} cols={cols} must be positive multiples of 16 "
+                                "(the reference resizes before this path, encode_decode.cpp:29-37)")
+    return (rows // 8) * (cols // 8) * 64, (rows // 16) * (cols // 16) * 64
 
 
 def encode_image(bgr, q_luma, q_chroma, out=None, stream=None):
@@ -82,16 +93,16 @@ def encode_image(bgr, q_luma, q_chroma, out=None, stream=None):
     [blocks, 64] in zigzag order (jpegamd_encode_image_dev)."""
     import torch
     rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
-    src = _dev(bgr, torch.uint8, "encode_image")
+    ny, nc = _plane_sizes(rows, cols)
+    src = _dev(bgr, torch.uint8, "encode_image", rows * cols * 3)
     if out is None:
-        nby, nbc = (rows // 8) * (cols // 8), (rows // 16) * (cols // 16)
-        out = tuple(torch.empty((n, 64), dtype=torch.int16, device=bgr.device) for n in (nby, nbc, nbc))
+        out = tuple(torch.empty((n // 64, 64), dtype=torch.int16, device=bgr.device) for n in (ny, nc, nc))
     ql, pl = _q(q_luma)
     qc, pc = _q(q_chroma)
     _lib.check(_lib.load().jpegamd_encode_image_dev(
         src, rows, cols, cols * 3, pl, pc,
-        _dev(out[0], torch.int16, "coef_y"), _dev(out[1], torch.int16, "coef_cb"),
-        _dev(out[2], torch.int16, "coef_cr"), _stream(stream)))
+        _dev(out[0], torch.int16, "coef_y", ny), _dev(out[1], torch.int16, "coef_cb", nc),
+        _dev(out[2], torch.int16, "coef_cr", nc), _stream(stream)))
     return out
 
 
@@ -112,14 +123,16 @@ def colour_planes(bgr, stream=None):
 def decode_image(coef_y, coef_cb, coef_cr, rows, cols, q_luma, q_chroma, out=None, stream=None):
     """inverse of encode_image -> cuda uint8 [rows, cols, 3] (jpegamd_decode_image_dev)."""
     import torch
+    rows, cols = int(rows), int(cols)
+    ny, nc = _plane_sizes(rows, cols)
     if out is None:
         out = torch.empty((rows, cols, 3), dtype=torch.uint8, device=coef_y.device)
     ql, pl = _q(q_luma)
     qc, pc = _q(q_chroma)
     _lib.check(_lib.load().jpegamd_decode_image_dev(
-        _dev(coef_y, torch.int16, "coef_y"), _dev(coef_cb, torch.int16, "coef_cb"),
-        _dev(coef_cr, torch.int16, "coef_cr"), int(rows), int(cols), pl, pc,
-        _dev(out, torch.uint8, "bgr"), int(cols) * 3, _stream(stream)))
+        _dev(coef_y, torch.int16, "coef_y", ny), _dev(coef_cb, torch.int16, "coef_cb", nc),
+        _dev(coef_cr, torch.int16, "coef_cr", nc), rows, cols, pl, pc,
+        _dev(out, torch.uint8, "bgr", rows * cols * 3), cols * 3, _stream(stream)))
     return out
 
 
@@ -153,16 +166,18 @@ def encode_plane(plane, q, stream=None):
     out = torch.empty((nb, 64), dtype=torch.int16, device=plane.device)
     qq, pq = _q(q)
     _lib.check(_lib.load().jpegamd_encode_plane_dev(
-        _dev(plane, torch.uint8, "plane"), rows, cols, cols, pq, out.data_ptr(), _stream(stream)))
+        _dev(plane, torch.uint8, "plane", rows * cols), rows, cols, cols, pq, out.data_ptr(), _stream(stream)))
     return out
 
 
 def decode_plane(coef, rows, cols, q, stream=None):
     import torch
+    rows, cols = int(rows), int(cols)
     out = torch.zeros((rows, cols), dtype=torch.uint8, device=coef.device)  # Mat::zeros, :793
     qq, pq = _q(q)
     _lib.check(_lib.load().jpegamd_decode_plane_dev(
-        _dev(coef, torch.int16, "coef"), int(rows), int(cols), pq, out.data_ptr(), int(cols), _stream(stream)))
+        _dev(coef, torch.int16, "coef", ((rows + 7) // 8) * ((cols + 7) // 8) * 64), rows, cols, pq, out.data_ptr(),
+        cols, _stream(stream)))
     return out
 
 
@@ -192,10 +207,12 @@ def time_image(bgr, coefs, bgr_out, q_luma, q_chroma, iters, stream=None):
     ql, pl = _q(q_luma)
     qc, pc = _q(q_chroma)
     e, d = ctypes.c_float(0), ctypes.c_float(0)
+    ny, nc = _plane_sizes(rows, cols)
     _lib.check(_lib.load().jpegamd_time_image_dev(
-        _dev(bgr, torch.uint8, "bgr"), rows, cols, cols * 3, pl, pc,
-        coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-        _dev(bgr_out, torch.uint8, "bgr_out"), int(iters), _stream(stream),
+        _dev(bgr, torch.uint8, "bgr", rows * cols * 3), rows, cols, cols * 3, pl, pc,
+        _dev(coefs[0], torch.int16, "coef_y", ny), _dev(coefs[1], torch.int16, "coef_cb", nc),
+        _dev(coefs[2], torch.int16, "coef_cr", nc),
+        _dev(bgr_out, torch.uint8, "bgr_out", rows * cols * 3), int(iters), _stream(stream),
         ctypes.byref(e), ctypes.byref(d)))
     return e.value, d.value
 
@@ -374,8 +391,8 @@ class Context:
     to call (use as a context manager, or call close())."""
 
     def __init__(self, device=0):
+        self._ctx = ctypes.c_void_p()  # (set before anything can raise: __del__ looks at it)
         self._lib = _lib.load()
-        self._ctx = ctypes.c_void_p()
         _lib.check(self._lib.jpegamd_context_create(int(device), ctypes.byref(self._ctx)))
 
     def close(self):
@@ -414,6 +431,9 @@ class Context:
                                                               ctypes.byref(r), ctypes.byref(c)))
         if out is None:
             out = np.empty((r.value, c.value, 3), np.uint8)
+        if not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous
+                and out.size == r.value * c.value * 3):
+            raise ValueError("decompress_image: `out` must be a C-contiguous uint8 array of rows x cols x 3")
         _lib.check(self._lib.jpegamd_context_decompress_image(self._ctx, buf.ctypes.data, buf.size, pl, pc,
                                                               out.ctypes.data, out.size, c.value * 3,
                                                               ctypes.byref(r), ctypes.byref(c)))

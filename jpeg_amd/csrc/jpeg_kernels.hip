@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void decode_plane_kernel(
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
                     if (r0 + r < rows && c0 + c < cols) // encode_decode.cpp:805
-                        plane[(size_t)(r0 + r) * stride + c0 + c] = (uint8_t)jm_clamp255(jm_magic_to_int(v[r * 8 + c]));
+                        plane[(size_t)(r0 + r) * stride + c0 + c] = (uint8_t)jm_clamp255(jm_magic_to_int32(v[r * 8 + c]));
         }
     }
 }
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(256) void dequant_idct_blocks_kernel(
     int4 *dst = reinterpret_cast<int4 *>(out + b * 64);
 #pragma unroll
     for (int k = 0; k < 16; ++k) // unclamped (the caller clamps, encode_decode.cpp:808)
-        dst[k] = make_int4(jm_magic_to_int(v[4 * k]), jm_magic_to_int(v[4 * k + 1]),
-                           jm_magic_to_int(v[4 * k + 2]), jm_magic_to_int(v[4 * k + 3]));
+        dst[k] = make_int4(jm_magic_to_int32(v[4 * k]), jm_magic_to_int32(v[4 * k + 1]),
+                           jm_magic_to_int32(v[4 * k + 2]), jm_magic_to_int32(v[4 * k + 3]));
 }
 
 // ------------------------------------------------------------------ host side

@@ -442,20 +442,31 @@ JM_HD int jm_magic_to_int(float u)
 {
     return (int)(int16_t)(jm_bits(u) & 0xFFFFu);
 }
+// MAGIC + 128 + x -> x + 128 as a full int (the legacy block boundary returns UNCLAMPED int32):
+// exact while |x + 128| < 2^22
+JM_HD int jm_magic_to_int32(float u)
+{
+    return (int)(u - JM_MAGIC);
+}
 
-// four jm_pixel_magic values -> four bytes saturated to 0..255 (std::clamp, :808)
+// four jm_pixel_magic values -> four bytes saturated to 0..255 (std::clamp, :808).
+// The value is taken from the float as a full integer (bits - bits(MAGIC): exact while
+// |x + 128| < 2^22) and narrowed with SATURATING packs, so a sum far outside int16 -- a corrupt
+// file, a caller's own coefficients -- still clamps to 0 or 255 like the reference's int
+// conversion + std::clamp (:705, :808) instead of wrapping to the opposite extreme.
 JM_HD uint32_t jm_pack4_u8(float a, float b, float c, float d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t ab = __builtin_amdgcn_perm(jm_bits(b), jm_bits(a), 0x05040100u);
-    uint32_t cd = __builtin_amdgcn_perm(jm_bits(d), jm_bits(c), 0x05040100u);
-    uint32_t sab, scd;
+    const uint32_t m = 0x4B400000u; // bits of JM_MAGIC
+    uint32_t ab, cd, sab, scd;
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(ab) : "v"(jm_bits(a) - m), "v"(jm_bits(b) - m));
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(cd) : "v"(jm_bits(c) - m), "v"(jm_bits(d) - m));
     asm("v_sat_pk_u8_i16 %0, %1" : "=v"(sab) : "v"(ab));
     asm("v_sat_pk_u8_i16 %0, %1" : "=v"(scd) : "v"(cd));
     return __builtin_amdgcn_perm(scd, sab, 0x05040100u);
 #else
-    return (uint32_t)jm_clamp255(jm_magic_to_int(a)) | ((uint32_t)jm_clamp255(jm_magic_to_int(b)) << 8) |
-           ((uint32_t)jm_clamp255(jm_magic_to_int(c)) << 16) | ((uint32_t)jm_clamp255(jm_magic_to_int(d)) << 24);
+    return (uint32_t)jm_clamp255(jm_magic_to_int32(a)) | ((uint32_t)jm_clamp255(jm_magic_to_int32(b)) << 8) |
+           ((uint32_t)jm_clamp255(jm_magic_to_int32(c)) << 16) | ((uint32_t)jm_clamp255(jm_magic_to_int32(d)) << 24);
 #endif
 }
 

@@ -354,6 +354,30 @@ def test_kernel_cuh_cpp_symbols(gpu, orc, tmp_path):
     _check_px(got_px, ref, "kernel.cuh decode")
 
 
+def test_out_of_range_idct_saturates_like_the_reference(gpu, orc):
+    """coefficient x Q products that take the IDCT beyond int16 (a corrupt .bin, or a
+    caller's own planes) must clamp like the reference's int conversion + std::clamp
+    (encode_decode.cpp:705, :808) -- white stays white -- and the legacy block boundary, which
+    returns UNCLAMPED int32 (kernel.cu:213), must return the large values themselves."""
+    import torch
+    import jpeg_amd
+    q = np.full(64, 255, np.int32)
+    rows = cols = 16
+    for dc, want in ((1100, 255), (-1100, 0), (32767, 255), (-32768, 0)):
+        cy = np.zeros((4, 64), np.int16)
+        cy[:, 0] = dc
+        cc = np.zeros((1, 64), np.int16)
+        plane = jpeg_amd.decode_plane(_t(cy, gpu), rows, cols, q).cpu().numpy()
+        assert (plane == want).all(), (dc, plane[0, :4])
+        assert np.array_equal(plane, orc.decode_plane(cy, rows, cols, q))
+        img = jpeg_amd.decode_image(_t(cy, gpu), _t(cc, gpu), _t(cc, gpu), rows, cols, q, q).cpu().numpy()
+        assert (img == want).all(), dc
+    coef = np.zeros((2, 64), np.float32)
+    coef[0, 0], coef[1, 0] = 2000.0, -2000.0
+    out = jpeg_amd.dequant_idct_blocks(coef, q)
+    assert (out[0] == 2000 * 255 // 8 + 128).all() and (out[1] == -(2000 * 255 // 8) + 128).all()
+
+
 def test_wikipedia_block(gpu):
     """known answers of jpeg_concept/jpeg_function.cpp:486-495 at QF=50."""
     import json
