@@ -190,6 +190,16 @@ int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_
                            const int32_t *d_sym_cr, size_t n_cr, int y_rows, int y_cols, int c_rows, int c_cols,
                            uint8_t *out, size_t cap, size_t *out_len);
 
+/* jpegamd_bin_decode with huffman_decode (encode_decode.cpp:468-482) on the device: .bin bytes
+ * on the host -> dims[6] and the three symbol streams in DEVICE memory (d_sym[k], cap[k] int32
+ * each; n[k] receives the count found -- if a buffer is missing or too small the call fails
+ * after setting all three).  The bit stream has no restart points: threads decode 256-bit
+ * subsequences from assumed starts and fall into step (prefix codes resynchronise); the same
+ * symbols as the bit-serial walk, pad-bit symbols included.  Dictionaries the device tables do
+ * not cover (a symbol outside int16) take the host decoder.  Synchronises the device. */
+int jpegamd_bin_decode_dev(const uint8_t *bin, size_t len, int32_t dims[6], int32_t *const d_sym[3], const size_t cap[3],
+                           size_t n[3]);
+
 /* main.cpp:96-133 with platform "GPU" (RGB2YCbCr, chromaSubsampling, mainEncode,
  * saveEncodedData) : image -> malloc'ed .bin bytes (release with jpegamd_free). */
 int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],

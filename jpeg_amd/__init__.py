@@ -7,5 +7,5 @@ from .api import (  # noqa: F401
     encode_image, decode_image, colour_planes, encode_images, decode_images, encode_plane, decode_plane,
     fdct_quant_blocks, dequant_idct_blocks, time_image, ZIGZAG,
     rle_encode_plane, rle_encode_planes, rle_decode_plane, encode_image_rle,
-    bin_encode, bin_encode_dev, bin_decode, compress_image, decompress_image, Context,
+    bin_encode, bin_encode_dev, bin_decode, bin_decode_dev, compress_image, decompress_image, Context,
 )

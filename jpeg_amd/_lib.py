@@ -53,6 +53,7 @@ SIGNATURES = {
                            _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t),
                            _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t),
                            _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_size_t)],
+    "jpegamd_bin_decode_dev": [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p],
     "jpegamd_quality_tables": [_c.c_int, _c.c_void_p, _c.c_void_p],
     "jpegamd_analysis_tables": [_c.c_int, _c.c_void_p, _c.c_void_p],
     "jpegamd_compress_image": [_c.c_void_p, _c.c_int, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_void_p,

@@ -356,6 +356,28 @@ def bin_decode(data):
     _lib.check(rc)
 
 
+def bin_decode_dev(data, device="cuda:0"):
+    """.bin bytes -> (dims[6], [sym_y, sym_cb, sym_cr] as cuda int32 tensors): huffman_decode on the
+    device (jpegamd_bin_decode_dev)."""
+    import torch
+    lib = _lib.load()
+    buf = np.frombuffer(data, np.uint8)
+    dims = np.zeros(6, np.int32)
+    n = (ctypes.c_size_t * 3)(0, 0, 0)
+    caps = [0, 0, 0]
+    syms = [None, None, None]
+    for _ in range(2):
+        ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() if t is not None and t.numel() else None for t in syms])
+        rc = lib.jpegamd_bin_decode_dev(buf.ctypes.data, buf.size, dims.ctypes.data, ptrs, (ctypes.c_size_t * 3)(*caps), n)
+        if rc == 0:
+            return dims, [t[:c] for t, c in zip(syms, n)]
+        if all(c <= cap and t is not None for c, cap, t in zip(n, caps, syms)):
+            _lib.check(rc)
+        caps = [max(int(c), 1) for c in n]
+        syms = [torch.empty(c, dtype=torch.int32, device=device) for c in caps]
+    _lib.check(rc)
+
+
 def compress_image(bgr, q_luma, q_chroma):
     """numpy uint8 [rows, cols, 3] on the HOST -> .bin bytes (jpegamd_compress_image)."""
     lib = _lib.load()

@@ -518,6 +518,83 @@ int get_i32(const uint8_t *p)
 
 int jpegamd_host_encode_plane(const int32_t *sym, size_t n, JpegamdPlaneCode &pl) { return encode_plane(sym, n, pl); }
 
+int jpegamd_bin_parse(const uint8_t *bin, size_t len, JpegamdBinParts &parts)
+{
+    if (len < 36)
+        return fail("bin_decode: shorter than the 9-int header");
+    for (int i = 0; i < 6; ++i)
+        parts.dims[i] = get_i32(bin + 4 * i);
+    size_t off = 36;
+    for (int c = 0; c < 3; ++c) {
+        const int l = get_i32(bin + 24 + 4 * c);
+        if (l < 0 || (size_t)l > len - off)
+            return fail("bin_decode: payload length runs past the end of the file");
+        parts.payload[c] = bin + off, parts.len[c] = (size_t)l;
+        off += (size_t)l;
+    }
+    if (len - off < 12)
+        return fail("bin_decode: dictionary sizes missing");
+    for (int c = 0; c < 3; ++c)
+        parts.dsz[c] = get_i32(bin + off + 4 * c);
+    off += 12;
+    for (int c = 0; c < 3; ++c) {
+        if (parts.dsz[c] < 0 || (size_t)parts.dsz[c] > (len - off) / 8)
+            return fail("bin_decode: dictionary runs past the end of the file");
+        parts.dict[c] = bin + off;
+        off += (size_t)parts.dsz[c] * 8;
+    }
+    return 0;
+}
+
+int jpegamd_host_decode_plane(const uint8_t *payload, size_t len, const uint8_t *dict, int dsz, int32_t *sym, size_t cap,
+                              size_t *n, unsigned threads)
+{
+    *n = 0;
+    std::unordered_map<int, int> freq; // :1279: insertion in file order
+    for (int i = 0; i < dsz; ++i)
+        freq[get_i32(dict + 8 * (size_t)i)] = get_i32(dict + 8 * (size_t)i + 4);
+    Tree t;
+    build_tree(std::vector<std::pair<int, int>>(freq.begin(), freq.end()), t); // decodeChannel, :664
+    if (len == 0)
+        return 0;
+    if (t.root < 0 || t.leaf(t.root))
+        return fail("bin_decode: a plane with fewer than two distinct symbols has no decodable code "
+                    "(the reference dereferences a null child here, encode_decode.cpp:474)");
+    PlaneDecoder dec(t, payload, (unsigned long long)len * 8);
+    *n = dec.decode(sym, sym ? cap : 0, threads ? threads : 1);
+    return 0;
+}
+
+int jpegamd_decode_tables(const uint8_t *dict, int dsz, JpegamdDecodeTables &out)
+{
+    std::unordered_map<int, int> freq; // :1279: insertion in file order
+    for (int i = 0; i < dsz; ++i)
+        freq[get_i32(dict + 8 * (size_t)i)] = get_i32(dict + 8 * (size_t)i + 4);
+    Tree t;
+    build_tree(std::vector<std::pair<int, int>>(freq.begin(), freq.end()), t); // decodeChannel, :664
+    if (t.root < 0 || t.leaf(t.root))
+        return 2;
+    for (size_t i = 0; i < t.value.size(); ++i)
+        if (t.leaf((int)i) && (t.value[i] < -32768 || t.value[i] > 32767))
+            return 2;
+    if (t.value.size() >= (1u << 24))
+        return 2;
+    out.left.assign(t.left.begin(), t.left.end());
+    out.right.assign(t.right.begin(), t.right.end());
+    out.value.assign(t.value.begin(), t.value.end());
+    out.root = t.root;
+    out.window.assign((size_t)1 << kDecodeWindow, 0);
+    for (int v = 0; v < (1 << kDecodeWindow); ++v) {
+        int cur = t.root, used = 0;
+        while (used < kDecodeWindow && !t.leaf(cur)) {
+            cur = ((v >> (kDecodeWindow - 1 - used)) & 1) ? t.right[cur] : t.left[cur];
+            ++used;
+        }
+        out.window[v] = t.leaf(cur) ? ((uint32_t)used << 24) | (uint32_t)(t.value[cur] + 32768) : (uint32_t)cur;
+    }
+    return 0;
+}
+
 int jpegamd_codes_from_order(const std::vector<int> &order, const uint32_t *count, JpegamdPlaneCode &pl,
                              std::vector<uint32_t> &cbits, std::vector<uint8_t> &clen, unsigned long long &total_bits)
 {

@@ -33,4 +33,42 @@ JPEGAMD_HIDDEN int jpegamd_bin_assemble(const JpegamdPlaneCode (&pl)[3], int y_r
 // run, ...).  Returns 0 with pl filled, 2 when this input needs the host path (a symbol
 // outside int16, a code longer than 32 bits, 2^32 symbols or more), 1 on error.
 JPEGAMD_HIDDEN int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode &pl);
+
+// Decoding tables of one plane from its dictionary as stored in the file (dsz (key, frequency)
+// int32 pairs): the tree built exactly as decodeChannel does (encode_decode.cpp:664: the pairs go
+// through a std::unordered_map first), flattened for the device decoder.
+//   window[v], v = the next kDecodeWindow bits of the stream (MSB first):
+//       length << 24 | (symbol + 32768)   the first whole code among those bits, or
+//       node                              (length 0) the inner node reached after all of them
+//   left / right / value: the tree, node by node (left < 0: a leaf carrying `value`)
+// Returns 0, or 2 when the device decoder does not cover this dictionary (fewer than two
+// symbols, a symbol outside int16): the caller then takes the host decoder.
+constexpr int kDecodeWindow = 12;
+struct JpegamdDecodeTables {
+    std::vector<uint32_t> window;
+    std::vector<int32_t> left, right, value;
+    int root = -1;
+};
+JPEGAMD_HIDDEN int jpegamd_decode_tables(const uint8_t *dict, int dsz, JpegamdDecodeTables &t);
+
+// The pieces of a .bin file (loadEncodedData's layout, encode_decode.cpp:1236-1296), bounds checked.
+struct JpegamdBinParts {
+    int32_t dims[6];
+    const uint8_t *payload[3];
+    size_t len[3];
+    const uint8_t *dict[3]; // dsz (key, frequency) int32 pairs each
+    int dsz[3];
+};
+JPEGAMD_HIDDEN int jpegamd_bin_parse(const uint8_t *bin, size_t len, JpegamdBinParts &parts);
+// huffman_decode of one plane on the host (PlaneDecoder, `threads` chunks); as the device form below
+JPEGAMD_HIDDEN int jpegamd_host_decode_plane(const uint8_t *payload, size_t len, const uint8_t *dict, int dsz,
+                                             int32_t *sym, size_t cap, size_t *n, unsigned threads);
+
+// huffman_decode of one plane on the device (entropy_decode_kernels.hip): payload = `len` bytes
+// on the HOST, every bit of every byte is decoded (the reference's loader knows no bit count,
+// encode_decode.cpp:1261-1263) into d_sym[0 .. cap) on the DEVICE; *n = the number of symbols
+// found (more than cap: the buffer was too small, only cap were written).  Returns 0, 2 when
+// the host decoder must take over, 1 on error.
+JPEGAMD_HIDDEN int jpegamd_device_decode_plane(const uint8_t *payload, size_t len, const uint8_t *dict, int dsz,
+                                               int32_t *d_sym, size_t cap, size_t *n);
 #endif

@@ -305,53 +305,57 @@ static int decompress_image_impl(const uint8_t *bin, size_t len, const int32_t q
     if (stride < (size_t)c * 3 || cap_bytes < (size_t)(r - 1) * stride + (size_t)c * 3)
         return jpegamd_fail("decompress_image: output buffer too small for %dx%d", r, c);
     const size_t nb[3] = {(size_t)(r / 8) * (c / 8), (size_t)(r / 16) * (c / 16), (size_t)(r / 16) * (c / 16)};
-    // A plane of nb blocks has at most 64 pairs per block (plus what up to 7 pad bits decode
-    // to), and no more symbols than payload bits.  Buffers are left uninitialised on purpose.
-    struct HostBuf {
-        int32_t *p = nullptr;
-        size_t size() const { return n; }
-        size_t n = 0;
-        ~HostBuf() { std::free(p); }
-    } sym[3];
-    size_t n[3] = {0, 0, 0};
-    for (int k = 0; k < 3; ++k) {
-        int32_t plen;
-        std::memcpy(&plen, bin + 24 + 4 * k, 4);
-        size_t cap = nb[k] * 128 + 16;
-        if (plen >= 0 && (size_t)plen * 8 < cap)
-            cap = (size_t)plen * 8;
-        sym[k].p = static_cast<int32_t *>(std::malloc((cap ? cap : 1) * sizeof(int32_t)));
-        if (!sym[k].p)
-            return jpegamd_fail("decompress_image: out of host memory");
-        sym[k].n = cap;
-    }
     StageTrace trace("decompress_image");
-    if (jpegamd_bin_decode(bin, len, dims, sym[0].p, sym[0].n, &n[0], sym[1].p, sym[1].n, &n[1], sym[2].p, sym[2].n,
-                           &n[2]))
-        return 1; // includes "more symbols than the plane sizes in the header allow"
-    trace.mark("entropy-decode");
-    for (int k = 0; k < 3; ++k)
-        sym[k].n = n[k];
-    // every buffer of the call up front: the planes then go through without a wait between them
-    DevMem d_coef[3], d_pairs[3], work[3], d_out;
-    size_t use[3], wbytes[3];
+    JpegamdBinParts parts;
+    if (jpegamd_bin_parse(bin, len, parts))
+        return 1;
+    // every buffer of the call up front: the planes then go through without a wait between them.
+    // A plane of nb blocks has at most 64 pairs per block (plus what up to 7 pad bits decode to),
+    // and no more symbols than payload bits.
+    DevMem d_coef[3], d_sym[3], work[3], d_out;
+    size_t cap[3], wbytes[3];
     for (int k = 0; k < 3; ++k) {
-        const size_t np = sym[k].size() / 2; // an odd trailing symbol has no run: dropped
-        use[k] = np < nb[k] * 64 + 8 ? np : nb[k] * 64 + 8; // pairs beyond that cannot reach the plane
+        cap[k] = nb[k] * 128 + 16;
+        if (parts.len[k] * 8 < cap[k])
+            cap[k] = parts.len[k] * 8;
         wbytes[k] = jpegamd_rle_workspace_bytes(nb[k]);
-        if (d_coef[k].alloc(nb[k] * 128) || d_pairs[k].alloc(use[k] * 8) || work[k].alloc(wbytes[k]))
+        if (d_coef[k].alloc(nb[k] * 128) || d_sym[k].alloc(cap[k] * 4) || work[k].alloc(wbytes[k]))
             return jpegamd_fail("decompress_image: out of device memory");
     }
     if (d_out.alloc((size_t)r * c * 3))
         return jpegamd_fail("decompress_image: out of device memory");
+    // huffman_decode (encode_decode.cpp:468-482) on the device; a plane the device tables do not
+    // cover (or JPEGAMD_ENTROPY=host) is decoded on the host and its symbols uploaded
+    size_t n[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) {
-        if (use[k] && jpegamd_staged_copy_linear(d_pairs[k].p, sym[k].p, use[k] * 8, true)) // returns when the data is there
+        int rc = entropy_on_host() ? 2
+                                   : jpegamd_device_decode_plane(parts.payload[k], parts.len[k], parts.dict[k],
+                                                                 parts.dsz[k], d_sym[k].as<int32_t>(), cap[k], &n[k]);
+        if (rc == 2) {
+            HostSymbols sym;
+            if (!sym.resize(cap[k]))
+                return jpegamd_fail("decompress_image: out of host memory");
+            rc = jpegamd_host_decode_plane(parts.payload[k], parts.len[k], parts.dict[k], parts.dsz[k], sym.data(), cap[k],
+                                           &n[k], 16);
+            const size_t have = n[k] < cap[k] ? n[k] : cap[k];
+            if (!rc && have && jpegamd_staged_copy_linear(d_sym[k].p, sym.data(), have * 4, true))
+                return 1;
+        }
+        if (rc)
             return 1;
-        if (jpegamd_rle_decode_plane_dev(d_pairs[k].as<int32_t>(), use[k], nb[k], d_coef[k].as<int16_t>(), work[k].p,
+        if (n[k] > cap[k])
+            return jpegamd_fail("decompress_image: plane %d decodes to %zu symbols, more than its %zu blocks can hold", k,
+                                n[k], nb[k]);
+    }
+    trace.mark("entropy-decode");
+    for (int k = 0; k < 3; ++k) {
+        const size_t np = n[k] / 2; // an odd trailing symbol has no run: dropped
+        const size_t use = np < nb[k] * 64 + 8 ? np : nb[k] * 64 + 8; // pairs beyond that cannot reach the plane
+        if (jpegamd_rle_decode_plane_dev(d_sym[k].as<int32_t>(), use, nb[k], d_coef[k].as<int16_t>(), work[k].p,
                                          wbytes[k], nullptr))
             return 1;
     }
-    trace.mark("upload+run-length");
+    trace.mark("run-length");
     if (jpegamd_decode_image_dev(d_coef[0].as<int16_t>(), d_coef[1].as<int16_t>(), d_coef[2].as<int16_t>(), r, c,
                                  q_luma, q_chroma, d_out.as<uint8_t>(), (size_t)c * 3, nullptr))
         return 1;
@@ -367,6 +371,47 @@ int jpegamd_bin_encode_dev(const int32_t *d_sym_y, size_t n_y, const int32_t *d_
                            uint8_t *out, size_t cap, size_t *out_len)
 {
     return jpegamd_guarded("bin_encode_dev", [&] { return bin_encode_dev_impl(d_sym_y, n_y, d_sym_cb, n_cb, d_sym_cr, n_cr, y_rows, y_cols, c_rows, c_cols, out, cap, out_len); });
+}
+
+static int bin_decode_dev_impl(const uint8_t *bin, size_t len, int32_t dims[6], int32_t *const d_sym[3],
+                               const size_t cap[3], size_t n[3])
+{
+    if (!bin || !dims || !d_sym || !cap || !n)
+        return jpegamd_fail("bin_decode_dev: null pointer");
+    n[0] = n[1] = n[2] = 0;
+    JpegamdBinParts parts;
+    if (jpegamd_bin_parse(bin, len, parts))
+        return 1;
+    std::memcpy(dims, parts.dims, sizeof parts.dims);
+    bool small = false;
+    for (int k = 0; k < 3; ++k) {
+        int rc = entropy_on_host() ? 2
+                                   : jpegamd_device_decode_plane(parts.payload[k], parts.len[k], parts.dict[k],
+                                                                 parts.dsz[k], d_sym[k], d_sym[k] ? cap[k] : 0, &n[k]);
+        if (rc == 2) { // the host decoder's cases: see jpegamd_decode_tables
+            HostSymbols sym;
+            const size_t c = d_sym[k] ? cap[k] : 0;
+            if (!sym.resize(c))
+                return jpegamd_fail("bin_decode_dev: out of host memory");
+            rc = jpegamd_host_decode_plane(parts.payload[k], parts.len[k], parts.dict[k], parts.dsz[k], c ? sym.data() : nullptr,
+                                           c, &n[k], 16);
+            const size_t have = n[k] < c ? n[k] : c;
+            if (!rc && have && jpegamd_staged_copy_linear(d_sym[k], sym.data(), have * 4, true))
+                return 1;
+        }
+        if (rc)
+            return 1;
+        small = small || n[k] > cap[k] || !d_sym[k];
+    }
+    if (small)
+        return jpegamd_fail("bin_decode: symbol buffer too small (the counts needed are in n[0..2])");
+    return 0;
+}
+
+int jpegamd_bin_decode_dev(const uint8_t *bin, size_t len, int32_t dims[6], int32_t *const d_sym[3], const size_t cap[3],
+                           size_t n[3])
+{
+    return jpegamd_guarded("bin_decode_dev", [&] { return bin_decode_dev_impl(bin, len, dims, d_sym, cap, n); });
 }
 
 int jpegamd_compress_image(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
