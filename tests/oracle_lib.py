@@ -23,10 +23,13 @@ def _p(a):
     return C.c_void_p(a.ctypes.data)
 
 
-def _build(so, directory):
+def _build(so, directory, refresh=False):
+    """refresh: run make even when the library exists (its Makefile knows what it is built from)"""
+    import subprocess
     if not os.path.exists(so):
-        import subprocess
         subprocess.check_call(["make", "-C", directory], stdout=subprocess.DEVNULL)
+    elif refresh:
+        subprocess.call(["make", "-C", directory], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return C.CDLL(so)
 
 
@@ -255,7 +258,7 @@ class Reference:
 
 class KernelMathModel:
     def __init__(self):
-        self.lib = L = _build(MODEL_SO, os.path.join(ROOT, "tests", "model"))
+        self.lib = L = _build(MODEL_SO, os.path.join(ROOT, "tests", "model"), refresh=True)
         for f in (L.jmm_check_const_div, L.jmm_check_round, L.jmm_check_quant):
             f.restype = C.c_long
 
@@ -271,6 +274,12 @@ class KernelMathModel:
         cand = C.c_long(0)
         self.lib.jmm_fwd_colour_fast(_p(img), C.c_size_t(img.size // 3), _p(out), C.byref(cand))
         return out, cand.value
+
+    def fwd_colour_fast_table(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.empty_like(img)
+        self.lib.jmm_fwd_colour_fast_table(_p(img), C.c_size_t(img.size // 3), _p(out))
+        return out
 
     def inv_colour(self, img):
         img = np.ascontiguousarray(img, np.uint8)
