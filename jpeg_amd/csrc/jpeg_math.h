@@ -416,7 +416,7 @@ JM_HD void jm_quantise_block(float (&x)[64], const float *inv100q)
 #pragma unroll
 #endif
     for (int i = 0; i < 64; ++i) {
-        float r = (x[i] + JM_MAGIC) - JM_MAGIC;
+        float r = jm_rint(x[i]); // round to nearest even, what (x + MAGIC) - MAGIC does in two operations
         x[i] = jm_fma(r, inv100q[i], JM_MAGIC);
     }
 }
@@ -450,20 +450,20 @@ JM_HD int jm_magic_to_int32(float u)
 }
 
 // four jm_pixel_magic values -> four bytes saturated to 0..255 (std::clamp, :808).
-// The value is taken from the float as a full integer (bits - bits(MAGIC): exact while
-// |x + 128| < 2^22) and narrowed with SATURATING packs, so a sum far outside int16 -- a corrupt
-// file, a caller's own coefficients -- still clamps to 0 or 255 like the reference's int
-// conversion + std::clamp (:705, :808) instead of wrapping to the opposite extreme.
+// u - MAGIC is x + 128 as an exact float integer (while |x + 128| < 2^22) and v_cvt_pk_u8_f32
+// converts with SATURATION into the byte it is told (tools/cvt_pk_u8_probe.hip), so a sum far
+// outside int16 -- a corrupt file, a caller's own coefficients -- still clamps to 0 or 255
+// like the reference's int conversion + std::clamp (:705, :808) instead of wrapping to the
+// opposite extreme.  Two instructions per sample, no packing permutes.
 JM_HD uint32_t jm_pack4_u8(float a, float b, float c, float d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t m = 0x4B400000u; // bits of JM_MAGIC
-    uint32_t ab, cd, sab, scd;
-    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(ab) : "v"(jm_bits(a) - m), "v"(jm_bits(b) - m));
-    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(cd) : "v"(jm_bits(c) - m), "v"(jm_bits(d) - m));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(sab) : "v"(ab));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(scd) : "v"(cd));
-    return __builtin_amdgcn_perm(scd, sab, 0x05040100u);
+    uint32_t r;
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(r) : "v"(a - JM_MAGIC));
+    asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(r) : "v"(b - JM_MAGIC));
+    asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(r) : "v"(c - JM_MAGIC));
+    asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(r) : "v"(d - JM_MAGIC));
+    return r;
 #else
     return (uint32_t)jm_clamp255(jm_magic_to_int32(a)) | ((uint32_t)jm_clamp255(jm_magic_to_int32(b)) << 8) |
            ((uint32_t)jm_clamp255(jm_magic_to_int32(c)) << 16) | ((uint32_t)jm_clamp255(jm_magic_to_int32(d)) << 24);
@@ -533,10 +533,10 @@ JM_HD void jm_fwd_colour_fast(float p0, float p1, float p2, float &uy, float &cb
     uy = t.sy + JM_MAGIC;
     t.ry = t.sy - (uy - JM_MAGIC);
     t.sb = jm_fma(p2, 0.5f, jm_fma(p1, -0.3313f, jm_fma(p0, -0.1687f, JM_CHROMA_BIAS)));
-    cb = (t.sb + JM_MAGIC) - JM_MAGIC;
+    cb = jm_rint(t.sb); // nearest even like a magic add, one operation
     t.rb = jm_fma(jm_abs(cb), -JM_CB_SLOPE, t.sb - cb);
     t.sr = jm_fma(p2, -0.0813f, jm_fma(p1, -0.4187f, jm_fma(p0, 0.5f, JM_CHROMA_BIAS)));
-    cr = (t.sr + JM_MAGIC) - JM_MAGIC;
+    cr = jm_rint(t.sr);
     t.rr = t.sr - cr;
 }
 
@@ -693,6 +693,25 @@ JM_HD uint32_t jm_ypair(uint32_t y4) // {Y_I, Y_J} as uint16 pair from four pack
 JM_HD void jm_inv_row4_fast(uint32_t y4, const JmChromaPk &a, const JmChromaPk &b,
                             uint32_t &w0, uint32_t &w1, uint32_t &w2)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One register {Y0, Y1} serves the three adds of a pixel pair: the operand-half selectors of
+    // the packed add pick {Y0,Y0}, {Y0,Y1} or {Y1,Y1}; the second saturating pack of every output
+    // dword writes the upper half of the first one's register (SDWA), so no permute assembles it.
+    const uint32_t y01 = jm_ypair<0, 1>(y4), y23 = jm_ypair<2, 3>(y4);
+    uint32_t s0, s1, s2, s3, s4, s5;
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(s0) : "v"(y01), "v"(a.d01));
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(s1) : "v"(y01), "v"(a.d20));
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(s2) : "v"(y01), "v"(a.d12));
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(s3) : "v"(y23), "v"(b.d01));
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(s4) : "v"(y23), "v"(b.d20));
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(s5) : "v"(y23), "v"(b.d12));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(w0) : "v"(s0));
+    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w0) : "v"(s1));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(w1) : "v"(s2));
+    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w1) : "v"(s3));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(w2) : "v"(s4));
+    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w2) : "v"(s5));
+#else
     uint32_t h0 = jm_add_sat_u8x2(jm_ypair<0, 0>(y4), a.d01);
     uint32_t h1 = jm_add_sat_u8x2(jm_ypair<0, 1>(y4), a.d20);
     uint32_t h2 = jm_add_sat_u8x2(jm_ypair<1, 1>(y4), a.d12);
@@ -702,6 +721,7 @@ JM_HD void jm_inv_row4_fast(uint32_t y4, const JmChromaPk &a, const JmChromaPk &
     w0 = jm_pack_lo16(h0, h1);
     w1 = jm_pack_lo16(h2, h3);
     w2 = jm_pack_lo16(h4, h5);
+#endif
 }
 
 // the same four pixels by the exact path: integer chroma terms, and the reference's

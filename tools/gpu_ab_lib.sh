@@ -1,0 +1,14 @@
+# A/B of two builds of the library on one box: tools/ab/lib_<name>.so, alternating; prints value, encode, decode
+set -o pipefail
+mkdir -p gpurun_out
+for rep in 1 2 3; do
+for name in "$@"; do
+  cp tools/ab/lib_$name.so jpeg_amd/libjpeg_amd.so || exit 1
+  timeout -k 10 300 python bench.py --steps 20 --no-cpu > gpurun_out/ab.json 2> gpurun_out/ab.err || { tail -20 gpurun_out/ab.err; exit 1; }
+  python - "$name" <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/ab.json"))
+print(sys.argv[1], round(d["value"]), "step %.4f" % d["ms_per_step"], "enc %.4f dec %.4f" % (d["roofline"]["encode_ms"], d["roofline"]["decode_ms"]), "rle %.4f" % d["rle_variant"]["ms"])
+PY
+done
+done
