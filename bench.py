@@ -40,6 +40,20 @@ def measured_traffic(rows, cols, quality, kernel):
     return table.get(f"{rows}x{cols}_qf{quality}", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
+def valu_issue(rows, cols, quality, kernel, ms):
+    """What actually bounds the fused kernels: VALU issue.  Instructions per launch from the committed
+    SQ counter pass (profiles/r02_e_pmc_sq.json), cycles per instruction and SIMD at the 2.4 GHz peak
+    clock from the live kernel time; a SIMD issues at most one VALU instruction per 4 cycles."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "r02_e_pmc_sq.json")))
+        n = table[f"{rows}x{cols}_qf{quality}"][kernel]["SQ_INSTS_VALU"]
+    except (OSError, KeyError, ValueError):
+        return None
+    simds, clock_hz = 256 * 4, 2.4e9
+    return {"SQ_INSTS_VALU_per_launch": n, "cycles_per_instruction_and_simd": ms * 1e-3 * clock_hz / (n / simds),
+            "issue_limit_cycles": 4.0, "clock_assumed_GHz": 2.4}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -162,6 +176,8 @@ def main():
     ap.add_argument("--quality", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the worst-case input and the run-length variant (a profile of the two fused kernels alone)")
     args = ap.parse_args()
 
     # --gpus N > 1 with no launcher around this process (no WORLD_SIZE): start the N ranks
@@ -261,7 +277,7 @@ def main():
     # SURVEY 8d config 2 asks for a second generator beside the headline one: i.i.d. uniform
     # bytes (dense coefficients, more rounding ties).  Reported, never the headline value.
     worst = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         noise = synth_image(rows, cols, 1, "noise", device=dev)
         jpeg_amd.time_image(noise, coefs, rec, qy, qc, 10)
         n_enc, n_dec = jpeg_amd.time_image(noise, coefs, rec, qy, qc, max(10, args.steps))
@@ -274,7 +290,7 @@ def main():
     # three planes.  Its written bytes are data dependent, so it is reported on its own and never
     # mixed into `value`.
     rle = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         rle = rle_variant(lib, _lib, torch, dev, stream, enc_args, coefs, rows, cols, max(10, args.steps))
 
     if rank == 0:
@@ -302,6 +318,7 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic(rows, cols, args.quality, dominant),
                          "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_ENC * npix,
+                         "valu_issue": valu_issue(rows, cols, args.quality, dominant, max(enc_ms, dec_ms)),
                          "encode_ms": enc_ms, "decode_ms": dec_ms,
                          "encode_GBs": enc_gbs, "decode_GBs": dec_gbs,
                          "enc_plus_dec_frac_of_peak": (BYTES_PER_PIXEL_ENC + BYTES_PER_PIXEL_DEC) * npix
