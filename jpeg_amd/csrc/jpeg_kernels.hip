@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     // current one is in its chroma round, so neither a workgroup launch nor a cold first fetch
     // sits between two tiles.  Every wave leaves the loop when its next tile is beyond the image.
     const int tile_step = gridDim.x * kWavesPerWg;
+    // When the wave count is a multiple of the tiles per row a wave would meet the same tile
+    // column every time -- and the right-most column may be a partial, cheaper tile (3840 = 7.5
+    // tiles): the column is therefore rotated by the round number (a rotation within a tile row
+    // keeps the assignment one to one).
+    const int skew = (tile_step % tiles_x) == 0 ? 1 : 0;
+    int round_no = 0;
     int tx = tile % tiles_x, ty = tile / tiles_x;
     uint8_t *stage = lds + wave * kWaveLds; // Y rows (8 x 512) alias the staging area
     uint8_t *cbuf = stage + kStageBytes;    // Cb: 8 x 256, Cr: 8 x 256
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     const int x0 = tx * kWaveTileW;
     const int next_tile = tile + tile_step;
     has_next = next_tile < n_tiles;
-    const int next_tx = has_next ? next_tile % tiles_x : tx;
+    const int next_tx = has_next ? (next_tile % tiles_x + skew * (round_no + 1)) % tiles_x : tx;
     next_ty = has_next ? next_tile / tiles_x : ty;
     next_off0 = lane_offset(next_tx, 0), next_off1 = lane_offset(next_tx, 1);
 
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     }
     if (!has_next)
         break;
-    tile = next_tile, tx = next_tx, ty = next_ty;
+    tile = next_tile, tx = next_tx, ty = next_ty, ++round_no;
     lane_off0 = next_off0, lane_off1 = next_off1;
     } // tiles of this wave
 }
@@ -343,6 +349,8 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     // persistent like the encoder: a wave takes tiles tile, tile + tile_step, ... and fetches the
     // chroma coefficients of its next tile during the current one's last luma round
     const int tile_step = gridDim.x * kWavesPerWg;
+    const int skew = (tile_step % tiles_x) == 0 ? 1 : 0; // as in the encoder: rotate the tile column per round
+    int round_no = 0;
     int tx = tile % tiles_x, ty = tile / tiles_x;
     uint8_t *stage = lds + wave * kWaveLds;
     uint8_t *cbuf = stage + kStageBytes;
@@ -365,7 +373,8 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     const int x0 = tx * kWaveTileW;
     const int next_tile = tile + tile_step;
     const bool has_next = next_tile < n_tiles;
-    const int next_tx = has_next ? next_tile % tiles_x : tx, next_ty = has_next ? next_tile / tiles_x : ty;
+    const int next_tx = has_next ? (next_tile % tiles_x + skew * (round_no + 1)) % tiles_x : tx;
+    const int next_ty = has_next ? next_tile / tiles_x : ty;
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
         const bool luma = it > 0;
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(256, 3) void decode_image_kernel(
     }
     if (!has_next)
         break;
-    tile = next_tile, tx = next_tx, ty = next_ty;
+    tile = next_tile, tx = next_tx, ty = next_ty, ++round_no;
     } // tiles of this wave
 }
 
