@@ -169,13 +169,28 @@ __global__ __launch_bounds__(kThreads) void hd_sync_kernel(Stream s, const uint3
 __global__ __launch_bounds__(1024) void hd_scan_kernel(uint32_t *__restrict__ v, uint32_t n,
                                                        unsigned long long *__restrict__ total)
 {
+    // one workgroup, eight consecutive counts per thread and pass: a plane of 8192^2 has about
+    // 110 000 subsequences, i.e. 14 passes
+    constexpr uint32_t kPer = 8;
     __shared__ unsigned long long wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long carry = 0;
-    for (uint32_t base = 0; base < n; base += 1024) { // uniform trip count
-        const uint32_t i = base + threadIdx.x;
-        const unsigned long long x = i < n ? v[i] : 0;
-        unsigned long long inc = x;
+    for (uint32_t base = 0; base < n; base += 1024 * kPer) { // uniform trip count
+        const uint32_t i = base + threadIdx.x * kPer;
+        uint32_t x[kPer];
+        if (i + kPer <= n) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(v + i), b = *reinterpret_cast<const uint4 *>(v + i + 4);
+            x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; ++j)
+                x[j] = i + j < n ? v[i + j] : 0u;
+        }
+        unsigned long long own = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j)
+            own += x[j];
+        unsigned long long inc = own;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned long long y = __shfl_up(inc, d, 64);
@@ -193,8 +208,13 @@ __global__ __launch_bounds__(1024) void hd_scan_kernel(uint32_t *__restrict__ v,
         __syncthreads();
         // offsets beyond 32 bits cannot be reached: the caller's buffer (cap) is far smaller and
         // the emit pass drops what lies beyond it
-        if (i < n)
-            v[i] = (uint32_t)(carry + before + inc - x < 0xFFFFFFFFull ? carry + before + inc - x : 0xFFFFFFFFull);
+        unsigned long long run = carry + before + inc - own;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) {
+            if (i + j < n)
+                v[i + j] = (uint32_t)(run < 0xFFFFFFFFull ? run : 0xFFFFFFFFull);
+            run += x[j];
+        }
         carry += all;
     }
     if (threadIdx.x == 0)
@@ -243,8 +263,10 @@ int jpegamd_device_decode_plane(const uint8_t *payload, size_t len, const uint8_
     const uint32_t n_wg = (n_sub + kThreads - 1) / kThreads;
     const size_t nodes = tab.left.size();
     DevMem d_pay, d_tab, d_work;
-    // work: total (8 B), changed flag (+ pad), sub_start, sub_count (n_sub each), wg ends a/b (n_wg each)
-    const size_t work_words = 4 + 2 * (size_t)n_sub + 2 * (size_t)n_wg;
+    // work: total (8 B), changed flag (+ pad), sub_count (16-byte aligned: the scan reads it four at a
+    // time), sub_start (n_sub each, rounded up to four), wg ends a/b (n_wg each)
+    const size_t n_sub_pad = ((size_t)n_sub + 3) & ~(size_t)3;
+    const size_t work_words = 4 + 2 * n_sub_pad + 2 * (size_t)n_wg;
     if (d_pay.alloc(((size_t)n_words + 2) * 4) || d_tab.alloc((tab.window.size() + 3 * nodes) * 4) ||
         d_work.alloc(work_words * 4))
         return jpegamd_fail("entropy decode: out of device memory");
@@ -266,8 +288,8 @@ int jpegamd_device_decode_plane(const uint8_t *payload, size_t len, const uint8_
     JPEGAMD_HIPCHK(hipMemcpy(d_value, tab.value.data(), nodes * 4, hipMemcpyHostToDevice));
     unsigned long long *total = d_work.as<unsigned long long>();
     uint32_t *changed = d_work.as<uint32_t>() + 2;
-    uint32_t *sub_start = changed + 2, *sub_count = sub_start + n_sub;
-    uint32_t *ends_a = sub_count + n_sub, *ends_b = ends_a + n_wg;
+    uint32_t *sub_count = changed + 2, *sub_start = sub_count + n_sub_pad;
+    uint32_t *ends_a = sub_start + n_sub_pad, *ends_b = ends_a + n_wg;
     JPEGAMD_HIPCHK(hipMemsetAsync(d_work.p, 0, 16, nullptr));
     const Stream s{d_pay.as<uint32_t>(), n_words, n_bits, d_left, d_right, d_value};
     hipLaunchKernelGGL(hd_sync_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, s, d_window, n_sub, sub_start, sub_count,

@@ -14,8 +14,9 @@ namespace {
 // hipMemcpy on pageable memory moves about 5 GB/s on the box (8192^2: 40 ms each way, far
 // more than every kernel together).  Four worker threads, each with two pinned 4 MiB staging
 // buffers and its own stream, copy row ranges instead: the CPU fills (or drains) one buffer
-// while the DMA engine moves the other.  The pool is created once per process and device
-// and serialises concurrent callers.
+// while the DMA engine moves the other.  There is one pool per device (created at its first
+// use, kept for the life of the process): callers on different GPUs neither serialise on one
+// another nor recreate each other's streams; concurrent callers on ONE device take turns.
 class StagedCopier {
 public:
     // `rows` rows of `width` bytes between a dense device buffer and host rows `hpitch` apart
@@ -151,22 +152,38 @@ private:
     }
 };
 
-StagedCopier g_copier;
+constexpr int kMaxDevices = 16; // more GPUs than any node of this kind has
+StagedCopier g_copiers[kMaxDevices];
+
+StagedCopier *copier_of_current_device()
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) {
+        (void)jpegamd_fail("staged copy: no current device, or a device index beyond %d", kMaxDevices - 1);
+        return nullptr;
+    }
+    return &g_copiers[device];
+}
 
 } // namespace
 
 int jpegamd_staged_copy(void *dev, uint8_t *host, size_t hpitch, size_t width, size_t rows, bool to_device)
 {
-    return g_copier.copy(dev, host, hpitch, width, rows, to_device);
+    StagedCopier *c = copier_of_current_device();
+    return c ? c->copy(dev, host, hpitch, width, rows, to_device) : 1;
 }
 
-int jpegamd_staged_copy_warm() { return g_copier.warm(); }
+int jpegamd_staged_copy_warm()
+{
+    StagedCopier *c = copier_of_current_device();
+    return c ? c->warm() : 1;
+}
 
 // one contiguous range: whole 4 KiB rows through the staged copier, the tail directly
 int jpegamd_staged_copy_linear(void *dev, void *host, size_t bytes, bool to_device)
 {
     const size_t tail = bytes % 4096, head = bytes - tail;
-    if (head && g_copier.copy(dev, static_cast<uint8_t *>(host), 4096, 4096, head / 4096, to_device))
+    if (head && jpegamd_staged_copy(dev, static_cast<uint8_t *>(host), 4096, 4096, head / 4096, to_device))
         return 1;
     if (tail) {
         uint8_t *d = static_cast<uint8_t *>(dev) + head, *h = static_cast<uint8_t *>(host) + head;
