@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kThreads) void sym_hist_kernel(const int32_t *__res
         } else {
             atomicAdd(&count[s + 32768], 1u);
             atomicMin(&first[s + 32768], i);
+            atomicOr(bad, 2u); // a key outside the window: the host then needs the whole tables
         }
     }
     __syncthreads();
@@ -210,13 +211,19 @@ int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode
     const uint32_t hist_grid = std::min<uint32_t>((n32 + kThreads - 1) / kThreads, 2048);
     hipLaunchKernelGGL(sym_hist_kernel, dim3(hist_grid), dim3(kThreads), 0, nullptr, d_sym, n32, d_count, d_first, d_bad);
     JPEGAMD_HIPCHK(hipGetLastError());
+    // Counters back to the host: the flags first; unless a key lay outside the LDS window (which
+    // coefficients and runs of an image never do) only the window's 2 x 8 KB instead of 2 x 256 KB.
     std::vector<uint32_t> h(2 * kKeys + 1);
-    JPEGAMD_HIPCHK(hipMemcpy(h.data(), d_count, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (h[2 * kKeys])
+    JPEGAMD_HIPCHK(hipMemcpy(&h[2 * kKeys], d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (h[2 * kKeys] & 1u)
         return 2; // a symbol outside int16: the host path has the general tables
+    const bool whole = (h[2 * kKeys] & 2u) != 0;
+    const int w0 = whole ? 0 : 32768 - kWin / 2, wn = whole ? kKeys : kWin; // keys [w0, w0 + wn) may be in use
+    JPEGAMD_HIPCHK(hipMemcpy(h.data() + w0, d_count + w0, (size_t)wn * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    JPEGAMD_HIPCHK(hipMemcpy(h.data() + kKeys + w0, d_first + w0, (size_t)wn * sizeof(uint32_t), hipMemcpyDeviceToHost));
     // distinct symbols in first-occurrence order: the insertion sequence of the reference's map
     std::vector<int> order;
-    for (int k = 0; k < kKeys; ++k)
+    for (int k = w0; k < w0 + wn; ++k)
         if (h[k])
             order.push_back(k - 32768);
     const uint32_t *first = h.data() + kKeys;
@@ -241,8 +248,9 @@ int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode
         return jpegamd_fail("entropy stage: out of device memory");
     uint32_t *d_cbits = tab.as<uint32_t>();
     uint8_t *d_clen = reinterpret_cast<uint8_t *>(d_cbits + kKeys);
-    JPEGAMD_HIPCHK(hipMemcpy(d_cbits, cbits.data(), kKeys * 4, hipMemcpyHostToDevice));
-    JPEGAMD_HIPCHK(hipMemcpy(d_clen, clen.data(), kKeys, hipMemcpyHostToDevice));
+    // (only the entries of keys in use are ever read)
+    JPEGAMD_HIPCHK(hipMemcpy(d_cbits + w0, cbits.data() + w0, (size_t)wn * 4, hipMemcpyHostToDevice));
+    JPEGAMD_HIPCHK(hipMemcpy(d_clen + w0, clen.data() + w0, (size_t)wn, hipMemcpyHostToDevice));
     JPEGAMD_HIPCHK(hipMemsetAsync(out.p, 0, words * 4, nullptr));
     hipLaunchKernelGGL(sym_bits_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, d_sym, n32, d_clen, sums.as<uint32_t>());
     hipLaunchKernelGGL(wg_offsets_kernel, dim3(1), dim3(1024), 0, nullptr, sums.as<uint32_t>(), n_wg,
@@ -250,6 +258,12 @@ int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode
     hipLaunchKernelGGL(sym_pack_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, d_sym, n32, d_cbits, d_clen,
                        offs.as<unsigned long long>(), out.as<uint32_t>());
     JPEGAMD_HIPCHK(hipGetLastError());
-    JPEGAMD_HIPCHK(hipMemcpy(pl.payload.data(), out.p, bytes, hipMemcpyDeviceToHost));
+    if (bytes >= (1u << 20)) { // through the pinned staging buffers: pageable hipMemcpy moves a fifth of that
+        JPEGAMD_HIPCHK(hipDeviceSynchronize());
+        if (jpegamd_staged_copy_linear(out.p, pl.payload.data(), bytes, false))
+            return 1;
+    } else {
+        JPEGAMD_HIPCHK(hipMemcpy(pl.payload.data(), out.p, bytes, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
