@@ -275,12 +275,6 @@ class KernelMathModel:
         self.lib.jmm_fwd_colour_fast(_p(img), C.c_size_t(img.size // 3), _p(out), C.byref(cand))
         return out, cand.value
 
-    def fwd_colour_fast_table(self, img):
-        img = np.ascontiguousarray(img, np.uint8)
-        out = np.empty_like(img)
-        self.lib.jmm_fwd_colour_fast_table(_p(img), C.c_size_t(img.size // 3), _p(out))
-        return out
-
     def inv_colour(self, img):
         img = np.ascontiguousarray(img, np.uint8)
         out = np.empty_like(img)

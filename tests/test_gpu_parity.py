@@ -57,6 +57,44 @@ def _check_px(got, want, what, lsb=1):
     return bad
 
 
+_U = np.arange(8)
+_BASIS = np.cos((2 * _U[None, :] + 1) * _U[:, None] * np.pi / 16) * np.where(_U[:, None] == 0, 1 / np.sqrt(2), 1.0) * 0.5
+
+
+def _exact_plane(coef_zz, q, rows, cols):
+    """the inverse transform of a whole plane in float64 (+ 128): what the pixels are as real numbers"""
+    nat = _natural(np.asarray(coef_zz).reshape(-1, 64)).astype(np.float64) * np.asarray(q, np.float64).reshape(1, 64)
+    px = np.einsum("un,buv,vm->bnm", _BASIS, nat.reshape(-1, 8, 8), _BASIS) + 128.0
+    bh, bw = (rows + 7) // 8, (cols + 7) // 8
+    return px.reshape(bh, bw, 8, 8).transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8)[:rows, :cols]
+
+
+def _check_plane_px(got, want, coef_zz, q, what):
+    """One decoded plane against the oracle's: +-1 everywhere.  Samples whose real value is an
+    exact x.5 are counted apart: there the reference's result is decided by the rounding errors
+    of its 64-term float sum (idct, encode_decode.cpp:577-588).  In a block with ONE coefficient
+    (DC only: every pixel of a flat block at a low quality factor) the sum lands below the tie
+    (cu*cv = 0.49999997f) and the kernels reproduce that: no difference is accepted there.  In a
+    block with more coefficients whose other terms cancel at that pixel (+a, then -a in float)
+    the reference lands on either side; the kernels go toward zero, +-1.  Every other difference
+    falls under the PIXEL_PPM bar as before.  Returns (differences at such ties, others)."""
+    got, want = np.asarray(got, np.int32), np.asarray(want, np.int32)
+    assert got.shape == want.shape
+    rows, cols = got.shape
+    d = np.abs(got - want)
+    assert d.max(initial=0) <= 1, f"{what}: sample off by {d.max()}"
+    exact = _exact_plane(coef_zz, q, rows, cols)
+    tie = np.abs(exact - np.floor(exact) - 0.5) < 1e-6
+    bh, bw = (rows + 7) // 8, (cols + 7) // 8
+    single = (np.asarray(coef_zz).reshape(-1, 64) != 0).sum(1).reshape(bh, bw) <= 1
+    single = np.repeat(np.repeat(single, 8, axis=0), 8, axis=1)[:rows, :cols]
+    bad_single = int(((d != 0) & tie & single).sum())
+    assert bad_single == 0, f"{what}: {bad_single} exact ties of one-coefficient blocks differ"
+    at_tie, other = int(((d != 0) & tie).sum()), int(((d != 0) & ~tie).sum())
+    assert other <= max(4, PIXEL_PPM * d.size // 1_000_000), f"{what}: {other} of {d.size} samples differ away from exact ties"
+    return at_tie, other
+
+
 def _model_image(model, orc, bgr, qy, qc):
     """what the kernels must produce bit for bit: colour (exact) + model transform"""
     ycc = orc.rgb2ycbcr(bgr)
