@@ -169,6 +169,52 @@ def test_image_vs_oracle(gpu, orc, model, kind, seed, rows, cols, qf):
         assert (coefs[1] == 0).all() and (coefs[2] == 0).all()
 
 
+def _other_images(kind, rows, cols, seed):
+    """inputs the two generators do not make: flat areas, hard edges, saturated colours, ramps"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    if kind == "flat":      # one colour per 16x16 MCU
+        img = np.repeat(np.repeat(rng.integers(0, 256, (rows // 16, cols // 16, 3)), 16, 0), 16, 1)
+    elif kind == "edges":   # random rectangles of saturated colours on a flat ground
+        img = np.full((rows, cols, 3), rng.integers(0, 256, 3))
+        for _ in range(40):
+            r0, c0 = rng.integers(0, rows), rng.integers(0, cols)
+            img[r0:r0 + rng.integers(1, 40), c0:c0 + rng.integers(1, 80)] = rng.choice([0, 255, 128, 1, 254], 3)
+    elif kind == "ramp":    # slow ramps, a different slope per channel
+        img = np.stack([(xx * (c + 1) // 3 + yy * (3 - c) // 2 + seed) % 256 for c in range(3)], -1)
+    else:                   # "text": black strokes one and two pixels wide on white
+        img = np.full((rows, cols, 3), 255)
+        img[(yy % 7 == 0) | (xx % 5 == 0) | ((xx + yy) % 11 < 2)] = 0
+    return np.ascontiguousarray(img.astype(np.uint8))
+
+
+@pytest.mark.parametrize("kind", ["flat", "edges", "ramp", "text"])
+@pytest.mark.parametrize("qf", [3, 17, 30, 50, 72, 93, 100])
+def test_other_image_kinds_vs_oracle(gpu, orc, model, kind, qf):
+    """Contents the synthetic generators do not produce, across the quality range: coefficients
+    +-1 under the COEF_PPM bar and equal to the host model bit for bit; the oracle's coefficients
+    decoded by the GPU: planes by _check_plane_px, the image == the colour stage of those planes."""
+    import jpeg_amd
+    rows, cols = 96, 272
+    bgr = _other_images(kind, rows, cols, 100 * qf + len(kind))
+    qy, qc = jpeg_amd.quality_tables(qf)
+    coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(bgr, gpu), qy, qc)]
+    want = orc.encode_image(bgr, qy, qc)
+    for g, w, n in zip(coefs, want, "Y Cb Cr".split()):
+        _check_coef(g, w, f"{kind} QF={qf} {n}")
+    for g, m in zip(coefs, _model_image(model, orc, bgr, qy, qc)):
+        assert np.array_equal(g, m)
+    planes = []
+    for w, (r, c), q, n in zip(want, ((rows, cols), (rows // 2, cols // 2), (rows // 2, cols // 2)), (qy, qc, qc), "Y Cb Cr".split()):
+        pl = jpeg_amd.decode_plane(_t(w, gpu), r, c, q).cpu().numpy()
+        _check_plane_px(pl, orc.decode_plane(w, r, c, q), w, q, f"{kind} QF={qf} {n} plane")
+        planes.append(pl)
+    rec = jpeg_amd.decode_image(*(_t(c, gpu) for c in want), rows, cols, qy, qc).cpu().numpy()
+    up = lambda c: np.repeat(np.repeat(c, 2, axis=0), 2, axis=1)
+    ycc = np.ascontiguousarray(np.stack([planes[0], up(planes[1]), up(planes[2])], -1))
+    assert np.array_equal(rec, orc.ycbcr2rgb(ycc))
+
+
 @pytest.mark.parametrize("grid", ["persistent", "pertile"])
 def test_image_of_exact_ties_only(gpu, orc, model, monkeypatch, grid):
     """Every pixel an exact x.5 tie of the forward colour transform (all 16 782 Y ties and
