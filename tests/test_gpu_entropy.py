@@ -16,13 +16,17 @@ def _streams(rng, nb, p_val=0.45, p_run=0.3, spread=1):
 
 
 @pytest.mark.parametrize("seed,nby,spread", [(1, 64, 1), (2, 4096, 1), (3, 70001, 37), (4, 262144, 1)])
-def test_device_container_equals_host_container(gpu, seed, nby, spread):
+def test_device_container_equals_host_container(gpu, orc, seed, nby, spread):
+    """... and the oracle's own writer (real std::unordered_map / std::priority_queue, the
+    reference's string of '0'/'1' characters) on the same streams: not only a self-comparison"""
     import jpeg_amd
     rng = np.random.default_rng(seed)
     sy, scb, scr = _streams(rng, nby, spread=spread), _streams(rng, nby // 4 + 1, 0.7), _streams(rng, nby // 4 + 1, 0.2, 0.6)
     want = jpeg_amd.bin_encode(sy, scb, scr, 128, 256)
     got = jpeg_amd.bin_encode_dev(*(torch.from_numpy(x).to(gpu) for x in (sy, scb, scr)), 128, 256)
     assert got == want
+    if nby <= 70001:  # (the oracle builds the bit string character by character)
+        assert got == orc.write_bin(sy, scb, scr, 128, 256)
 
 
 def test_edge_streams(gpu):
