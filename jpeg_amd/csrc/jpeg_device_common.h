@@ -181,6 +181,22 @@ __device__ __forceinline__ unsigned long long run_ends(const uint32_t (&w)[32])
     return ((unsigned long long)half[1] << 32) | half[0];
 }
 
+// The popcount of run_ends() without the mask: differing neighbours counted two per packed
+// instruction (16-bit halves), four instructions per dword instead of nine.
+__device__ __forceinline__ uint32_t count_pairs(const uint32_t (&w)[32])
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 one = {1, 1};
+    u16x2 acc = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 31; ++k) { // low half: value 2k != value 2k+1, high half: value 2k+1 != value 2k+2
+        const uint32_t x = w[k] ^ __builtin_amdgcn_alignbit(w[k + 1], w[k], 16);
+        acc += __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), one);
+    }
+    const uint32_t last = (w[31] ^ (w[31] >> 16)) & 0xFFFFu; // value 62 != value 63; position 63 always ends a run
+    return (uint32_t)acc.x + (uint32_t)acc.y + (last ? 2u : 1u);
+}
+
 // One task of the colour stage for one lane: 2 rows x 4 pixels of BGR -> the eight luma
 // values as magic floats (byte in the low 8 bits) and the two quads' sums of centred Cb, Cr
 // (RGB2YCbCr, encode_decode.cpp:39-75, and the sums of chromaSubsampling, :139-149).

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                 }
                 uint8_t *dst = luma ? counts.y + (size_t)(ty * 2 + it) * bw_y + bcol
                                     : (lane < 32 ? counts.cb : counts.cr) + (size_t)ty * bw_c + bcol;
-                *dst = (uint8_t)__builtin_popcountll(run_ends(w));
+                *dst = (uint8_t)count_pairs(w);
             }
         }
         wave_lds_fence();

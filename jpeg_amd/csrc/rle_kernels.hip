@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void rle_count_kernel(RleJob job, uint32_t *__
     const size_t blk0 = (size_t)(tile - pl.tile_begin) * kBlocksPerWg + wave * 64;
     uint32_t w[32];
     stage_blocks(pl.coef, blk0, pl.nb, lds + wave * 64 * kPitch, lane, w);
-    const uint32_t n = blk0 + lane < pl.nb ? (uint32_t)__builtin_popcountll(run_ends(w)) : 0u;
+    const uint32_t n = blk0 + lane < pl.nb ? count_pairs(w) : 0u;
     const uint32_t t = wave_sum32(n);
     if (lane == 0)
         wave_sums[wave] = t;
