@@ -116,15 +116,33 @@ def spawn_ranks(n, child_cmd, port=None, extra_env=None):
     return procs
 
 
-def run_as_launcher(n, argv):
+def run_as_launcher(n, argv, child_cmd=None):
     """`python bench.py --gpus N` without a launcher around it: be the launcher.  Relays rank
-    0's JSON line; the exit status is the worst of the ranks'."""
-    procs = spawn_ranks(n, [sys.executable, os.path.abspath(__file__)] + argv)
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
-    sys.stdout.write(out)
+    0's JSON line.  Exit status: 0 only if EVERY rank exited 0; a rank that died by a signal
+    (Popen reports -SIGNUM: a GPU abort is -6) or with a non-zero code makes the launcher fail with
+    that code's magnitude, and the ranks still running are terminated (they are fresh child
+    processes, never an exec) instead of being left to wait for a rendezvous or collective timeout."""
+    import threading
+    procs = spawn_ranks(n, child_cmd or [sys.executable, os.path.abspath(__file__)] + argv)
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # rank 0's pipe is drained while every rank is watched
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+                for q in pending:  # one rank failed: the others would only hang in the next collective
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(out[0] if out else "")
     sys.stdout.flush()
     return rc
 

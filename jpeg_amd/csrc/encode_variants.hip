@@ -375,7 +375,7 @@ __device__ __forceinline__ void xdl_transform_strip(const uint8_t *src, int pitc
                 jm_fdct8<102400, false>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const float x = (c[u] + JM_MAGIC) - JM_MAGIC;  // round(100 c), :284
+                    const float x = jm_rint(c[u]);                  // round(100 c), :284
                     const float q = jm_fma(x, qm[u], JM_MAGIC);     // roundf(c / Q), :306 (see jm_quantise_block)
                     *reinterpret_cast<uint16_t *>(stage + k.zoff[u] + (2 * nv + 16 * uu) * kStagePitch) = (uint16_t)jm_bits(q);
                 }
@@ -415,13 +415,17 @@ __global__ __launch_bounds__(256, 3) void encode_image_xdl_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
-    const int tile = blockIdx.x * kWavesPerWg + wave;
+    int tile = blockIdx.x * kWavesPerWg + wave;
     if (tile >= n_tiles)
         return; // whole wave leaves together; nothing else is shared between waves
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    // persistent like encode_image_kernel (jpeg_kernels.hip): tiles tile, tile + tile_step, ..., the first
+    // four tasks of the next tile fetched during the current one's last colour chunk
+    const int tile_step = gridDim.x * kWavesPerWg;
+    const int skew = (tile_step % tiles_x) == 0 ? 1 : 0;
+    int round_no = 0;
+    int tx = tile % tiles_x, ty = tile / tiles_x;
     uint8_t *ybuf = lds + wave * kWaveLdsX; // 8 luma rows (one strip); staging area during the transforms
     uint8_t *cbuf = ybuf + kXYBytes;        // Cb rows 0-7, Cr rows 8-15
-    const int x0 = tx * kWaveTileW;
     const int bw_y = cols >> 3, bw_c = cols >> 4;
 
     // matrix-pipe constants of this lane: column n = lane & 15 = 8*bsel + v, K-group lane >> 4 = blk
@@ -445,19 +449,35 @@ __global__ __launch_bounds__(256, 3) void encode_image_xdl_kernel(
 
     // ---- colour + 4:2:0: the task scheme of encode_image_kernel ---------------------------
     constexpr int kRing = 4;
-    auto task_load = [&](int T, U3 &a, U3 &b) {
-        T = T < 15 ? T : 15;
-        const int row = ty * 16 + 2 * (T >> 1);
-        int x = x0 + 4 * (lane + 64 * (T & 1));
+    auto lane_offset = [&](int tile_x, int h) {
+        int x = tile_x * kWaveTileW + 4 * (lane + 64 * h);
         x = x < cols - 4 ? x : cols - 4;
-        const uint8_t *p = bgr + (size_t)row * stride + (size_t)x * 3;
-        a = *reinterpret_cast<const U3 *>(p);
-        b = *reinterpret_cast<const U3 *>(p + stride);
+        return 3u * (uint32_t)x;
+    };
+    uint32_t lane_off0 = lane_offset(tx, 0), lane_off1 = lane_offset(tx, 1), next_off0 = 0, next_off1 = 0;
+    int next_ty = ty;
+    bool has_next = false;
+    auto task_load = [&](int T, int odd, U3 &a, U3 &b) { // odd == T & 1, a compile-time constant at every call
+        const bool ahead = T >= 16 && has_next;
+        const int row = ahead ? next_ty * 16 + 2 * ((T - 16) >> 1) : ty * 16 + 2 * ((T < 16 ? T : 14 + odd) >> 1);
+        const uint32_t off = odd ? (ahead ? next_off1 : lane_off1) : (ahead ? next_off0 : lane_off0);
+        const uint8_t *rowp = bgr + (size_t)row * stride;
+        a = *reinterpret_cast<const U3 *>(rowp + off);
+        b = *reinterpret_cast<const U3 *>(rowp + stride + off);
     };
     U3 ring_a[kRing], ring_b[kRing];
 #pragma unroll
     for (int i = 0; i < kRing; ++i)
-        task_load(i, ring_a[i], ring_b[i]);
+        task_load(i, i & 1, ring_a[i], ring_b[i]);
+
+#pragma unroll 1
+    for (;;) {
+    const int x0 = tx * kWaveTileW;
+    const int next_tile = tile + tile_step;
+    has_next = next_tile < n_tiles;
+    const int next_tx = has_next ? (next_tile % tiles_x + skew * (round_no + 1)) % tiles_x : tx;
+    next_ty = has_next ? next_tile / tiles_x : ty;
+    next_off0 = lane_offset(next_tx, 0), next_off1 = lane_offset(next_tx, 1);
 
 #pragma unroll 1
     for (int it = 0; it < 2; ++it) {
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(256, 3) void encode_image_xdl_kernel(
             U3 next_a[kRing], next_b[kRing];
 #pragma unroll
             for (int i = 0; i < kRing; ++i)
-                task_load(it * 8 + t0 + kRing + i, next_a[i], next_b[i]);
+                task_load(it * 8 + t0 + kRing + i, i & 1, next_a[i], next_b[i]);
 #pragma unroll
             for (int slot = 0; slot < kRing; ++slot) {
                 const int t = t0 + slot;
@@ -475,14 +495,14 @@ __global__ __launch_bounds__(256, 3) void encode_image_xdl_kernel(
                 if (x0 + 4 * g < cols) {
                     float ya[4], yb[4], sum_b[2], sum_r[2];
                     colour_task(ring_a[slot], ring_b[slot], ya, yb, sum_b, sum_r);
-                    uint8_t *y0 = ybuf + (2 * rp) * kXPitchY + 4 * g;
+                    volatile lds_u8 *y0 = (volatile lds_u8 *)(ybuf + (2 * rp) * kXPitchY + 4 * g);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         y0[j] = (uint8_t)jm_bits(ya[j]);
                         y0[kXPitchY + j] = (uint8_t)jm_bits(yb[j]);
                     }
                     // chromaSubsampling: truncating mean of the quad (:139-149)
-                    uint8_t *c0 = cbuf + (it * 4 + rp) * kXPitchC + 2 * g;
+                    volatile lds_u8 *c0 = (volatile lds_u8 *)(cbuf + (it * 4 + rp) * kXPitchC + 2 * g);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         c0[q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[q]));
@@ -516,6 +536,11 @@ __global__ __launch_bounds__(256, 3) void encode_image_xdl_kernel(
         xdl_transform_strip<2>(cbuf + 8 * kXPitchC, kXPitchC, ybuf, lane, k, qm,
                                reinterpret_cast<uint8_t *>(coef_cr + first), bw_c - tx * 32);
     }
+    if (!has_next)
+        break;
+    tile = next_tile, tx = next_tx, ty = next_ty, ++round_no;
+    lane_off0 = next_off0, lane_off1 = next_off1;
+    } // tiles of this wave
 }
 
 } // namespace

@@ -737,7 +737,8 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
         return fail("encode_image: null coefficient pointer");
     const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
     const int n_tiles = tiles_x * (rows / 16);
-    int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    const int grid_per_tile = (n_tiles + kWavesPerWg - 1) / kWavesPerWg; // one wave per tile
+    int grid = grid_per_tile;
     if (encoder_grid_persistent()) { // no more workgroups than are resident at once: 3 per CU (LDS)
         int cus = 0;
         if (jpegamd_cu_count(&cus))
@@ -753,7 +754,10 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
     }
     const Transform tr = transform_choice();
     if (tr != Transform::valu)
-        return jpegamd_launch_encode_variant(tr == Transform::mfma_f32 ? 1 : 2, grid, stream, start, stop, d_bgr, rows,
+        // the f32 matrix-core variant takes one tile per wave (never the capped grid: it would leave the
+        // tiles beyond 12 x CUs unwritten); the f16 row-pass variant loops over tiles like the kernel above
+        return jpegamd_launch_encode_variant(tr == Transform::mfma_f32 ? 1 : 2,
+                                             tr == Transform::mfma_f32 ? grid_per_tile : grid, stream, start, stop, d_bgr, rows,
                                              cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
     const auto kern = &encode_image_kernel<false, false>;
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop, 0, d_bgr, rows, cols,

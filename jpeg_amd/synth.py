@@ -46,3 +46,39 @@ def synth_image(rows, cols, seed=0, kind="photo", device="cpu"):
             v = v + (h & 7) + ((h >> 3) & 7) - 7
         out[:, :, c] = v.clamp_(0, 255).to(torch.uint8)
     return out
+
+
+def upscale_integer_bilinear(src, factor):
+    """uint8 [n, m, 3] -> uint8 [n * factor, m * factor, 3] with an integer bilinear filter
+    (weights k / factor, rounded once at the end): no library's resize filter is involved, so the
+    "Lena-derived" inputs of SURVEY.md 8d (config 5 and the size ladder of image_resize.py:19-29)
+    are the same bytes on every machine.  Works on the tensor's device."""
+    f = int(factor)
+    s = src.to(torch.int64)
+    dev = src.device
+
+    def taps(n):
+        idx = torch.arange(n * f, device=dev)
+        i0 = (idx // f).clamp(max=n - 1)
+        return i0, (i0 + 1).clamp(max=n - 1), idx % f
+
+    r0, r1, wr = taps(s.shape[0])
+    c0, c1, wc = taps(s.shape[1])
+    rows = s[r0] * (f - wr).view(-1, 1, 1) + s[r1] * wr.view(-1, 1, 1)  # scaled by f
+    img = (rows[:, c0] * (f - wc).view(1, -1, 1) + rows[:, c1] * wc.view(1, -1, 1) + f * f // 2) // (f * f)
+    return img.to(torch.uint8).contiguous()
+
+
+def lena_upscaled(factor, device="cpu", path=None):
+    """The committed 1024^2 Lena photograph (tests/golden/lena_color_1024.png, the reference's
+    img/lena_color_1024.png) in cv::imread channel order, x `factor` by upscale_integer_bilinear:
+    4 -> 4096^2 (config 5), 8 -> 8192^2."""
+    import os
+    import numpy as np
+    from PIL import Image
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                            "lena_color_1024.png")
+    rgb = np.array(Image.open(path).convert("RGB"))
+    bgr = torch.from_numpy(np.ascontiguousarray(rgb[:, :, ::-1])).to(device)
+    return upscale_integer_bilinear(bgr, factor) if int(factor) > 1 else bgr.contiguous()

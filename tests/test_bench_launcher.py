@@ -46,3 +46,33 @@ def test_bench_under_an_outer_launcher_does_not_spawn_again():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") == 1
+
+
+def test_launcher_reports_a_rank_killed_by_a_signal_and_ends_its_siblings():
+    """a rank that dies by a signal has a NEGATIVE Popen return code (a GPU abort is
+    -6); max() with healthy siblings' 0 used to turn that into exit status 0 with empty stdout,
+    and the siblings were left to wait for the rendezvous timeout.  Stand-in ranks: rank 0 kills
+    itself with SIGABRT, rank 1 would sleep for a minute."""
+    import time
+    import bench
+    child = [sys.executable, "-c",
+             "import os, signal, time\n"
+             "if os.environ['RANK'] == '0':\n"
+             "    os.kill(os.getpid(), signal.SIGABRT)\n"
+             "time.sleep(60)\n"]
+    t0 = time.perf_counter()
+    rc = bench.run_as_launcher(2, [], child_cmd=child)
+    assert rc == 6, rc
+    assert time.perf_counter() - t0 < 30, "the surviving rank was not terminated"
+
+
+def test_launcher_fails_when_a_rank_other_than_zero_fails(capsys):
+    import bench
+    child = [sys.executable, "-c",
+             "import os, sys\n"
+             "print('{\"rank0\": true}') if os.environ['RANK'] == '0' else sys.exit(3)\n"]
+    rc = bench.run_as_launcher(2, [], child_cmd=child)
+    assert rc == 3
+    child_ok = [sys.executable, "-c", "import os\nif os.environ['RANK'] == '0': print('{\"ok\": 1}')\n"]
+    assert bench.run_as_launcher(3, [], child_cmd=child_ok) == 0
+    assert '{"ok": 1}' in capsys.readouterr().out

@@ -40,6 +40,11 @@ def test_quality_sweep(gpu, orc, qf):
     up = lambda c: np.repeat(np.repeat(c, 2, axis=0), 2, axis=1)
     ycc = np.ascontiguousarray(np.stack([planes[0], up(planes[1]), up(planes[2])], -1))
     assert np.array_equal(rec, orc.ycbcr2rgb(ycc)), f"QF={qf}: decoded image is not YCbCr2RGB of the decoded planes"
+    # north_star: "MSE/PSNR identical to 0.01 dB" -- the GPU's image against the reference path's image
+    # (the oracle decoding the oracle's own coefficients), at every quality factor
+    ref_img = orc.decode_image(*want, 128, 256, qy, qc)
+    p_gpu, p_ref = orc.psnr(orc.mse(bgr, rec)), orc.psnr(orc.mse(bgr, ref_img))
+    assert abs(p_gpu - p_ref) < 0.01, f"QF={qf}: PSNR {p_gpu:.4f} dB against the reference path's {p_ref:.4f} dB"
 
 
 def test_gray_image_has_flat_chroma(gpu, orc):
@@ -198,6 +203,32 @@ def test_config5_full_size_quality(gpu, orc, qf):
     _strip_parity(orc, bgr, coefs, rec, qy, qc, (0, 129, 255), f"QF={qf}")
     again = jpeg_amd.encode_image(bgr, qy, qc)
     assert all(torch.equal(x, y) for x, y in zip(coefs, again))  # deterministic
+
+
+@pytest.mark.parametrize("qf", [10, 50, 90])
+def test_config5_lena_upscaled(gpu, orc, qf):
+    """config 5 on ITS input: the Lena photograph x4 (integer bilinear, jpeg_amd.synth.lena_upscaled:
+    the committed 1024^2 golden input, no library resize filter) = 4096^2.  Strip parity against the
+    oracle, the file round trip, and PSNR of the GPU's image against the reference path's on the strips."""
+    import jpeg_amd
+    from jpeg_amd.synth import lena_upscaled
+    bgr = lena_upscaled(4, device=gpu)
+    rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
+    assert (rows, cols) == (4096, 4096)
+    qy, qc = jpeg_amd.quality_tables(qf)
+    coefs = jpeg_amd.encode_image(bgr, qy, qc)
+    rec = jpeg_amd.decode_image(*coefs, rows, cols, qy, qc)
+    mcu_rows = (0, 77, 128, 255)
+    _strip_parity(orc, bgr, coefs, rec, qy, qc, mcu_rows, f"Lena x4 QF={qf}")
+    # PSNR over the sampled strips: the GPU's pixels against the reference path's (oracle end to end)
+    src = np.concatenate([bgr[my * 16:(my + 1) * 16].cpu().numpy() for my in mcu_rows])
+    got = np.concatenate([rec[my * 16:(my + 1) * 16].cpu().numpy() for my in mcu_rows])
+    ref = np.concatenate([orc.decode_image(*orc.encode_image(bgr[my * 16:(my + 1) * 16].cpu().numpy(), qy, qc), 16, cols, qy, qc)
+                          for my in mcu_rows])
+    assert abs(orc.psnr(orc.mse(src, got)) - orc.psnr(orc.mse(src, ref))) < 0.01
+    if qf == 50:
+        data = jpeg_amd.compress_image(bgr.cpu().numpy(), qy, qc)
+        assert np.array_equal(jpeg_amd.decompress_image(data, qy, qc), rec.cpu().numpy())
 
 
 def test_device_entry_points_can_be_captured_in_a_hip_graph(gpu):

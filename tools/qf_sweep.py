@@ -11,15 +11,10 @@ import jpeg_amd
 jpeg_amd.init(0)
 dev = torch.device("cuda:0")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rgb = np.array(Image.open(os.path.join(root, "tests", "golden", "lena_color_1024.png")).convert("RGB"))
-src = torch.from_numpy(np.ascontiguousarray(rgb[:, :, ::-1])).to(dev).to(torch.int64)  # B, G, R
+from jpeg_amd.synth import lena_upscaled
 F = 4
-n = src.shape[0]
-idx = torch.arange(n * F, device=dev)
-i0 = (idx // F).clamp(max=n - 1); i1 = (i0 + 1).clamp(max=n - 1); w = idx % F
-rowsI = (src[i0] * (F - w).view(-1, 1, 1) + src[i1] * w.view(-1, 1, 1))            # scaled by F
-img = (rowsI[:, i0] * (F - w).view(1, -1, 1) + rowsI[:, i1] * w.view(1, -1, 1) + F * F // 2) // (F * F)
-img = img.to(torch.uint8).contiguous()
+img = lena_upscaled(F, device=dev)
+n = img.shape[0] // F
 R = C = n * F
 print(f"# QF sweep, {R}x{C} image (Lena 1024^2 x{F}, integer bilinear), MI355X; kernel times in sequence")
 print("# QF  enc_us  dec_us  Mpixel/s(kernels)  nnz/block Y Cb Cr      pairs/block Y Cb Cr    bin_bytes  ratio  PSNR_dB")
