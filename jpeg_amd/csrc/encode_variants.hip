@@ -1,6 +1,7 @@
-// encode_variants.hip -- the two opt-in encoders whose transform runs (partly) on the matrix
-// pipes (JPEGAMD_TRANSFORM=mfma / xdl).  Same tile, colour stage, parity tests and C ABI as
-// encode_image_kernel in jpeg_kernels.hip; kept for measurement.
+// encode_variants.hip -- the opt-in encoder whose transform runs as f32 matrix instructions
+// (JPEGAMD_TRANSFORM=mfma).  Same tile, colour stage, parity tests and C ABI as encode_image_kernel
+// in jpeg_kernels.hip; kept for measurement.  The other opt-in form, the row pass on the
+// 16-bit matrix pipe (JPEGAMD_TRANSFORM=xdl), is a template option of encode_image_kernel itself.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -267,289 +268,15 @@ __global__ __launch_bounds__(256, 3) void encode_image_mfma_kernel(
     }
 }
 
-// =============================================================================
-// Fused encoder with the ROW pass of the DCT on the 16-bit matrix pipe.
-//
-// f32 MFMAs execute on the VALU's own lanes (see above), the 16-bit forms do not: they
-// run beside other waves' VALU work.  The pixels are integers, exact in f16, so the row
-// pass  D1[y][v] = sum_x P[y][x] a_v(x)  can run as v_mfma_f32_16x16x32_f16 without
-// losing anything: each constant is split into three f16 terms (33 bits), all products are
-// exact, and the sum is accumulated in f32 like the VALU chain's.  The column pass needs
-// its real-valued input at f32 precision, so it stays on the VALU (jm_fdct8 in-lane).
-//
-// One MFMA "unit" = 16 blocks = 128 px x 8 rows:
-//   A[m][k]  m = 4*quad + r (row 4h + r of the 32-px quad `quad`), k = 8*blk + x: lane
-//            (ga, m) supplies 8 consecutive bytes of one row.  A byte b in the low half of
-//            an f16 with a zero exponent IS the subnormal b * 2^-24, which the matrix pipe
-//            honours (tools/mfma_f16_layout_probe.hip): one v_perm per two samples.
-//   B[k][n]  n = 8*bsel + v: term t of 2^14 a_v(x) where blk == 2*nv + bsel, else 0.
-//   D[m][n]  lane (quad, n) gets rows 4h + 0..3 of block 4*quad + 2*nv + bsel, frequency v:
-//            after 2 (h) x 2 (nv) x 3 (terms) MFMAs it holds two whole columns D1[0..7][v],
-//            runs the column pass on them and owns coefficients (0..7, v) of two blocks.
-// Scale: 2^-24 * 2^14 = 2^-10, undone by the column pass's constants (100 * 1024; a power
-// of two, so they are the usual constants with another exponent).  The level shift
-// (-128 per sample) reaches v = 0 only and is the accumulator's initial value.
-// The accumulation order inside a 16-bit MFMA is not documented, so this kernel has no
-// bit-exact host replay: it is held to the oracle's bar only (+-1 LSB, <= 8 per million).
-// =============================================================================
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-struct XdlTable {
-    _Float16 c[3][8][8]; // [term][v][x]: 2^14 a_v(x) = c[0] + c[1] + c[2]
-};
-constexpr XdlTable make_xdl_table()
-{
-    XdlTable t{};
-    for (int v = 0; v < 8; ++v)
-        for (int x = 0; x < 8; ++x) {
-            const double a = jm_dct_basis_f64(v, x) * 16384.0;
-            const _Float16 h = (_Float16)a;
-            const double r1 = a - (double)h;
-            const _Float16 m = (_Float16)r1;
-            const _Float16 l = (_Float16)(r1 - (double)m);
-            t.c[0][v][x] = h, t.c[1][v][x] = m, t.c[2][v][x] = l;
-        }
-    return t;
-}
-__device__ const XdlTable kXdlTable = make_xdl_table();
-
-constexpr int kXPitchY = 640;                  // 160 dwords: a row starts 32 banks after the one above
-constexpr int kXPitchC = 384;                  // 96 dwords: likewise for the 256-sample chroma rows
-constexpr int kXYBytes = 8 * kXPitchY;         // 5120: one strip of 8 luma rows; later the staging area
-constexpr int kXCBytes = 16 * kXPitchC;        // 6144: Cb rows 0-7, Cr rows 8-15
-constexpr int kWaveLdsX = kXYBytes + kXCBytes; // 11264
-static_assert(32 * kStagePitch <= kXYBytes, "staging (32 blocks at the 144 B pitch) must fit in the luma strip");
-
-struct XdlLane {
-    f16x8 b[3][2]; // B operands [term][nv]
-    f32x4 c0;      // accumulator start: the level shift for v = 0
-    int zoff[8];   // staging byte offset of coefficient (u, v) of this lane's block pair
-};
-
-// eight bytes -> eight f16 subnormals (byte * 2^-24)
-__device__ __forceinline__ f16x8 bytes_as_f16(uint2 raw)
-{
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 w = {__builtin_amdgcn_perm(0u, raw.x, 0x0C010C00u), __builtin_amdgcn_perm(0u, raw.x, 0x0C030C02u),
-               __builtin_amdgcn_perm(0u, raw.y, 0x0C010C00u), __builtin_amdgcn_perm(0u, raw.y, 0x0C030C02u)};
-    return __builtin_bit_cast(f16x8, w);
-}
-
-// NU units (16 blocks each) of one 8-row strip at `src`: row pass on the matrix pipe, column
-// pass + quantiser in-lane, 32 blocks at a time staged in zigzag order (144 B pitch) and stored as four
-// 1 KiB wave-contiguous pieces.  The staging area may alias `src`: every operand byte is
-// in registers before the first staged coefficient is written.
-template <int NU>
-__device__ __forceinline__ void xdl_transform_strip(const uint8_t *src, int pitch, uint8_t *stage, int lane,
-                                                    const XdlLane &k, const float (&qm)[8], uint8_t *dst, int n_ok)
-{
-    uint2 raw[NU][2];
-    const uint8_t *p = src + (lane & 3) * pitch + ((lane >> 2) & 3) * 32 + (lane >> 4) * 8;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            raw[u][h] = *reinterpret_cast<const uint2 *>(p + h * 4 * pitch + u * 128);
-    }
-    wave_lds_fence();
-    const int blk = lane >> 3;
-#pragma unroll
-    for (int round = 0; round < NU / 2; ++round) {
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu) {
-            f32x4 acc[2][2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f16x8 a = bytes_as_f16(raw[2 * round + uu][h]);
-#pragma unroll
-                for (int nv = 0; nv < 2; ++nv) {
-                    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, k.b[0][nv], k.c0, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, k.b[1][nv], d, 0, 0, 0);
-                    acc[h][nv] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, k.b[2][nv], d, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int nv = 0; nv < 2; ++nv) {
-                float c[8] = {acc[0][nv][0], acc[0][nv][1], acc[0][nv][2], acc[0][nv][3],
-                              acc[1][nv][0], acc[1][nv][1], acc[1][nv][2], acc[1][nv][3]};
-                jm_fdct8<102400, false>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float x = jm_rint(c[u]);                  // round(100 c), :284
-                    const float q = jm_fma(x, qm[u], JM_MAGIC);     // roundf(c / Q), :306 (see jm_quantise_block)
-                    *reinterpret_cast<uint16_t *>(stage + k.zoff[u] + (2 * nv + 16 * uu) * kStagePitch) = (uint16_t)jm_bits(q);
-                }
-            }
-        }
-        wave_lds_fence();
-        if (32 * round + 32 <= n_ok) { // the whole round lies inside the plane: reads first, then stores
-            uint4 d[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                d[i] = *reinterpret_cast<const uint4 *>(stage + (i * 8 + blk) * kStagePitch + (lane & 7) * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<uint4 *>(dst + round * 4096 + i * 1024 + lane * 16) = d[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (32 * round + i * 8 + blk < n_ok) {
-                    uint4 d = *reinterpret_cast<const uint4 *>(stage + (i * 8 + blk) * kStagePitch + (lane & 7) * 16);
-                    *reinterpret_cast<uint4 *>(dst + round * 4096 + i * 1024 + lane * 16) = d;
-                }
-            }
-        }
-        wave_lds_fence(); // staged blocks are read (in-order LDS) before the next round overwrites them
-    }
-}
-
-__global__ __launch_bounds__(256, 3) void encode_image_xdl_kernel(
-    const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
-    int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
-    int tiles_x, int n_tiles)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg * kWaveLdsX];
-    __shared__ __attribute__((aligned(16))) float qtab[128];
-    if (threadIdx.x < 128)
-        qtab[threadIdx.x] = qp.t[threadIdx.x >> 6].inv100q[threadIdx.x & 63];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform: tile arithmetic stays scalar
-    int tile = blockIdx.x * kWavesPerWg + wave;
-    if (tile >= n_tiles)
-        return; // whole wave leaves together; nothing else is shared between waves
-    // persistent like encode_image_kernel (jpeg_kernels.hip): tiles tile, tile + tile_step, ..., the first
-    // four tasks of the next tile fetched during the current one's last colour chunk
-    const int tile_step = gridDim.x * kWavesPerWg;
-    const int skew = (tile_step % tiles_x) == 0 ? 1 : 0;
-    int round_no = 0;
-    int tx = tile % tiles_x, ty = tile / tiles_x;
-    uint8_t *ybuf = lds + wave * kWaveLdsX; // 8 luma rows (one strip); staging area during the transforms
-    uint8_t *cbuf = ybuf + kXYBytes;        // Cb rows 0-7, Cr rows 8-15
-    const int bw_y = cols >> 3, bw_c = cols >> 4;
-
-    // matrix-pipe constants of this lane: column n = lane & 15 = 8*bsel + v, K-group lane >> 4 = blk
-    XdlLane k;
-    {
-        const int v = lane & 7, bsel = (lane >> 3) & 1, kg = lane >> 4;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const f16x8 term = *reinterpret_cast<const f16x8 *>(kXdlTable.c[t][v]);
-            const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int nv = 0; nv < 2; ++nv)
-                k.b[t][nv] = kg == 2 * nv + bsel ? term : zero;
-        }
-        const float lv = v == 0 ? -(float)JM_A0 : 0.0f; // recenterAroundZero (:289-298): -128 * 8 a_0 * 2^-10
-        k.c0 = f32x4{lv, lv, lv, lv};
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            k.zoff[u] = (4 * kg + bsel) * kStagePitch + 2 * kZZInv[u * 8 + v];
-    }
-
-    // ---- colour + 4:2:0: the task scheme of encode_image_kernel ---------------------------
-    constexpr int kRing = 4;
-    auto lane_offset = [&](int tile_x, int h) {
-        int x = tile_x * kWaveTileW + 4 * (lane + 64 * h);
-        x = x < cols - 4 ? x : cols - 4;
-        return 3u * (uint32_t)x;
-    };
-    uint32_t lane_off0 = lane_offset(tx, 0), lane_off1 = lane_offset(tx, 1), next_off0 = 0, next_off1 = 0;
-    int next_ty = ty;
-    bool has_next = false;
-    auto task_load = [&](int T, int odd, U3 &a, U3 &b) { // odd == T & 1, a compile-time constant at every call
-        const bool ahead = T >= 16 && has_next;
-        const int row = ahead ? next_ty * 16 + 2 * ((T - 16) >> 1) : ty * 16 + 2 * ((T < 16 ? T : 14 + odd) >> 1);
-        const uint32_t off = odd ? (ahead ? next_off1 : lane_off1) : (ahead ? next_off0 : lane_off0);
-        const uint8_t *rowp = bgr + (size_t)row * stride;
-        a = *reinterpret_cast<const U3 *>(rowp + off);
-        b = *reinterpret_cast<const U3 *>(rowp + stride + off);
-    };
-    U3 ring_a[kRing], ring_b[kRing];
-#pragma unroll
-    for (int i = 0; i < kRing; ++i)
-        task_load(i, i & 1, ring_a[i], ring_b[i]);
-
-#pragma unroll 1
-    for (;;) {
-    const int x0 = tx * kWaveTileW;
-    const int next_tile = tile + tile_step;
-    has_next = next_tile < n_tiles;
-    const int next_tx = has_next ? (next_tile % tiles_x + skew * (round_no + 1)) % tiles_x : tx;
-    next_ty = has_next ? next_tile / tiles_x : ty;
-    next_off0 = lane_offset(next_tx, 0), next_off1 = lane_offset(next_tx, 1);
-
-#pragma unroll 1
-    for (int it = 0; it < 2; ++it) {
-#pragma unroll 1
-        for (int t0 = 0; t0 < 8; t0 += kRing) {
-            U3 next_a[kRing], next_b[kRing];
-#pragma unroll
-            for (int i = 0; i < kRing; ++i)
-                task_load(it * 8 + t0 + kRing + i, i & 1, next_a[i], next_b[i]);
-#pragma unroll
-            for (int slot = 0; slot < kRing; ++slot) {
-                const int t = t0 + slot;
-                const int rp = t >> 1;
-                const int g = lane + 64 * (t & 1);
-                if (x0 + 4 * g < cols) {
-                    float ya[4], yb[4], sum_b[2], sum_r[2];
-                    colour_task(ring_a[slot], ring_b[slot], ya, yb, sum_b, sum_r);
-                    volatile lds_u8 *y0 = (volatile lds_u8 *)(ybuf + (2 * rp) * kXPitchY + 4 * g);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        y0[j] = (uint8_t)jm_bits(ya[j]);
-                        y0[kXPitchY + j] = (uint8_t)jm_bits(yb[j]);
-                    }
-                    // chromaSubsampling: truncating mean of the quad (:139-149)
-                    volatile lds_u8 *c0 = (volatile lds_u8 *)(cbuf + (it * 4 + rp) * kXPitchC + 2 * g);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        c0[q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[q]));
-                        c0[8 * kXPitchC + q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_r[q]));
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < kRing; ++i)
-                ring_a[i] = next_a[i], ring_b[i] = next_b[i];
-        }
-        wave_lds_fence();
-
-        // ---- luma strip `it`: 64 blocks ------------------------------------------------------
-        float qm[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            qm[u] = qtab[u * 8 + (lane & 7)];
-        uint8_t *dst = reinterpret_cast<uint8_t *>(coef_y + ((size_t)(ty * 2 + it) * bw_y + tx * 64) * 64);
-        xdl_transform_strip<4>(ybuf, kXPitchY, ybuf, lane, k, qm, dst, bw_y - tx * 64);
-    }
-    {
-        // ---- chroma: 32 blocks of Cb, 32 of Cr -------------------------------------------------
-        float qm[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            qm[u] = qtab[64 + u * 8 + (lane & 7)];
-        const size_t first = ((size_t)ty * bw_c + tx * 32) * 64;
-        xdl_transform_strip<2>(cbuf, kXPitchC, ybuf, lane, k, qm, reinterpret_cast<uint8_t *>(coef_cb + first),
-                               bw_c - tx * 32);
-        xdl_transform_strip<2>(cbuf + 8 * kXPitchC, kXPitchC, ybuf, lane, k, qm,
-                               reinterpret_cast<uint8_t *>(coef_cr + first), bw_c - tx * 32);
-    }
-    if (!has_next)
-        break;
-    tile = next_tile, tx = next_tx, ty = next_ty, ++round_no;
-    lane_off0 = next_off0, lane_off1 = next_off1;
-    } // tiles of this wave
-}
-
 } // namespace
 
 int jpegamd_launch_encode_variant(int variant, int grid, void *stream, hipEvent_t start, hipEvent_t stop,
                                   const uint8_t *d_bgr, int rows, int cols, size_t stride, const QuantPair &qp,
                                   int16_t *d_coef_y, int16_t *d_coef_cb, int16_t *d_coef_cr, int tiles_x, int n_tiles)
 {
-    auto kernel = variant == 1 ? encode_image_mfma_kernel : encode_image_xdl_kernel;
+    if (variant != 1)
+        return jpegamd_fail("encode variant %d is not in this translation unit", variant);
+    auto kernel = encode_image_mfma_kernel;
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop, 0, d_bgr, rows,
                           cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
     JPEGAMD_HIPCHK(hipGetLastError());

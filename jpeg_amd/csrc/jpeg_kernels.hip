@@ -38,6 +38,112 @@ __attribute__((visibility("hidden"))) int jpegamd_launch_encode_variant(
 
 namespace {
 
+// ------------------------------------------- row pass on the 16-bit matrix pipe
+// v_mfma_f32_16x16x32_f16 runs beside other waves' VALU work (the f32 forms do not: DESIGN.md 3),
+// and the encoder is bound by VALU issue, so the ROW pass of the forward DCT can leave the VALU:
+//   D[m][n] = sum_k A[m][k] B[k][n]      A: lane (m = l & 15, g = l >> 4) holds k = 8g .. 8g+7
+//                                        B: lane (n = l & 15, g = l >> 4) holds k = 8g .. 8g+7
+//                                        D: lane (n = l & 15, g = l >> 4) holds m = 4g .. 4g+3
+// B is DATA: lane l supplies the eight pixels of row y of ITS OWN block (lane = block, as in the
+// VALU transform) -- a byte in the low half of an f16 with a zero exponent is the subnormal
+// b * 2^-24, which the matrix pipe honours (tools/mfma_f16_layout_probe.hip), so an operand costs
+// one v_perm per two samples instead of one conversion per sample.  A is CONSTANT and block
+// diagonal: row m = 4g' + i is a_v(x) for v = 4*vh + i in the K-slots of lane group g' and zero
+// elsewhere, so D[4g' + i][n] = sum_x a_v(x) P[block (n, g')][y][x]: lane (n, g') receives four
+// frequencies of row y of its own block, and after 8 rows x 2 halves x 3 terms it holds all 64
+// row-pass outputs D1[y][v] in the registers the column pass (jm_fdct8, in-lane) works on.
+// Nothing crosses lanes and the staging is the VALU kernel's.  Each constant 2^14 a_v(x) is split
+// into three f16 terms (33 bits); products are exact, the sum is accumulated in f32.  Scale:
+// 2^-24 * 2^14 = 2^-10, undone by the column pass's constants (100 * 1024, a power of two times
+// the usual ones).  The level shift reaches v = 0 only and is that accumulator's initial value.
+// The accumulation order inside a 16-bit MFMA is not documented: this path is held to the oracle's
+// bar (+-1 LSB, <= 8 per million), not to the host model bit for bit.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct RowPassTable {
+    _Float16 c[3][8][8]; // [term][v][x]: 2^14 a_v(x) = c[0] + c[1] + c[2]
+};
+constexpr RowPassTable make_row_pass_table()
+{
+    RowPassTable t{};
+    for (int v = 0; v < 8; ++v)
+        for (int x = 0; x < 8; ++x) {
+            const double a = jm_dct_basis_f64(v, x) * 16384.0;
+            const _Float16 h = (_Float16)a;
+            const double r1 = a - (double)h;
+            const _Float16 m = (_Float16)r1;
+            const _Float16 l = (_Float16)(r1 - (double)m);
+            t.c[0][v][x] = h, t.c[1][v][x] = m, t.c[2][v][x] = l;
+        }
+    return t;
+}
+__device__ const RowPassTable kRowPassTable = make_row_pass_table();
+
+struct RowPassLane {
+    f16x8 a[3][2]; // A operands [term][v half]
+};
+
+__device__ __forceinline__ RowPassLane make_row_pass_lane(int lane)
+{
+    RowPassLane k;
+    const int m = lane & 15, g = lane >> 4;
+    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int vh = 0; vh < 2; ++vh) {
+            const f16x8 term = *reinterpret_cast<const f16x8 *>(kRowPassTable.c[t][4 * vh + (m & 3)]);
+            k.a[t][vh] = (m >> 2) == g ? term : zero;
+        }
+    return k;
+}
+
+// eight bytes -> eight f16 subnormals (byte * 2^-24)
+__device__ __forceinline__ f16x8 bytes_as_f16(uint2 raw)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = {__builtin_amdgcn_perm(0u, raw.x, 0x0C010C00u), __builtin_amdgcn_perm(0u, raw.x, 0x0C030C02u),
+               __builtin_amdgcn_perm(0u, raw.y, 0x0C010C00u), __builtin_amdgcn_perm(0u, raw.y, 0x0C030C02u)};
+    return __builtin_bit_cast(f16x8, w);
+}
+
+// the eight rows of the lane's block at src (pitch bytes apart) -> v[y * 8 + f] = 2^-10 * row-pass
+// output of row y, horizontal frequency f.  Runs for ALL lanes of the wave (a matrix instruction
+// is a wave-level operation); lanes whose block lies outside the image read whatever the LDS
+// holds -- bytes, hence finite -- and only their own accumulators see it.
+__device__ __forceinline__ void rows_fdct_matrix_pipe(const uint8_t *src, int pitch, const RowPassLane &k, float (&v)[64])
+{
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    // Four rows at a time, term by term over their 8 accumulators: a dependent 16x16x32 waits for its
+    // predecessor, 7 independent ones in between hide that (and only 4 operands are live).  (Rows in
+    // the order 0, 7, 1, 6 | 2, 5, 3, 4, so that the column pass's first butterflies can be issued
+    // under the second half's matrix instructions, measured no faster: profiles/r03_a_*.)
+    constexpr int kOrder[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f16x8 b[4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+            b[y] = bytes_as_f16(*reinterpret_cast<const uint2 *>(src + kOrder[4 * h + y] * pitch));
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int vh = 0; vh < 2; ++vh)
+                    acc[y][vh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.a[t][vh], b[y], t == 0 ? zero : acc[y][vh], 0, 0, 0);
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int vh = 0; vh < 2; ++vh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[kOrder[4 * h + y] * 8 + 4 * vh + i] = acc[y][vh][i];
+    }
+}
+
 // ------------------------------------------------------------- fused encoder
 // grid: one wave per 512x16 tile, 4 waves per workgroup.
 // kCounts: also write, per block, the number of (value, run) pairs run_length_encode
@@ -48,7 +154,8 @@ struct CountPlanes {
 };
 // kDump: stop after the colour stage and write the Y, Cb, Cr planes (RGB2YCbCr +
 // chromaSubsampling on their own: jpegamd_colour_planes_dev); `counts` then names the planes.
-template <bool kCounts, bool kDump>
+// kPipe: 0 = both DCT passes on the VALU; 1 = the row pass on the 16-bit matrix pipe (above)
+template <bool kCounts, bool kDump, int kPipe = 0>
 __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
     int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
@@ -113,6 +220,9 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
 #pragma unroll
     for (int i = 0; i < kRing; ++i)
         task_load(i, i & 1, ring_a[i], ring_b[i]);
+    RowPassLane rowpass;
+    if constexpr (kPipe == 1)
+        rowpass = make_row_pass_lane(lane);
 
 #pragma unroll 1
     for (;;) {
@@ -226,17 +336,30 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
         const int pitch = luma ? 512 : 256;
         const int bcol = luma ? tx * 64 + lane : tx * 32 + (lane & 31);
         const bool valid = bcol < (luma ? bw_y : bw_c);
-        if (valid) {
-            float v[64];
+        float v[64];
+        if constexpr (kPipe == 1)
+            rows_fdct_matrix_pipe(src, pitch, rowpass, v); // every lane: a matrix instruction is the wave's
+        if (kPipe == 1 || valid) { // matrix pipe: the whole wave, one basic block with the matrix instructions
+            if constexpr (kPipe == 1) {
+                // recenterAroundZero (:289-298) reaches horizontal frequency 0 only: each of the eight row
+                // sums of that column is short of -128 * 8 a_0 * 2^-10 = -a_0, the column's sum of 8 a_0 = 2 sqrt 2
+                jm_fdct8<102400, true, 282842712, 100000000>(v[0], v[8], v[16], v[24], v[32], v[40], v[48], v[56]);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                uint2 d = *reinterpret_cast<const uint2 *>(src + r * pitch);
-                v[r * 8 + 0] = ubyte_f32<0>(d.x), v[r * 8 + 1] = ubyte_f32<1>(d.x);
-                v[r * 8 + 2] = ubyte_f32<2>(d.x), v[r * 8 + 3] = ubyte_f32<3>(d.x);
-                v[r * 8 + 4] = ubyte_f32<0>(d.y), v[r * 8 + 5] = ubyte_f32<1>(d.y);
-                v[r * 8 + 6] = ubyte_f32<2>(d.y), v[r * 8 + 7] = ubyte_f32<3>(d.y);
+                for (int c = 1; c < 8; ++c)
+                    jm_fdct8<102400, false>(v[0 * 8 + c], v[1 * 8 + c], v[2 * 8 + c], v[3 * 8 + c],
+                                            v[4 * 8 + c], v[5 * 8 + c], v[6 * 8 + c], v[7 * 8 + c]);
+                jm_quantise_block(v, qtab + (luma ? 0 : 64));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    uint2 d = *reinterpret_cast<const uint2 *>(src + r * pitch);
+                    v[r * 8 + 0] = ubyte_f32<0>(d.x), v[r * 8 + 1] = ubyte_f32<1>(d.x);
+                    v[r * 8 + 2] = ubyte_f32<2>(d.x), v[r * 8 + 3] = ubyte_f32<3>(d.x);
+                    v[r * 8 + 4] = ubyte_f32<0>(d.y), v[r * 8 + 5] = ubyte_f32<1>(d.y);
+                    v[r * 8 + 6] = ubyte_f32<2>(d.y), v[r * 8 + 7] = ubyte_f32<3>(d.y);
+                }
+                block_fdct_quant(v, qtab + (luma ? 0 : 64));
             }
-            block_fdct_quant(v, qtab + (luma ? 0 : 64));
             // The staging area aliases the Y rows.  LDS instructions of one wave
             // retire in program order, so every lane's reads above are done before
             // the writes below; the fence only pins the compiler's order.
@@ -256,7 +379,8 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                 }
                 uint8_t *dst = luma ? counts.y + (size_t)(ty * 2 + it) * bw_y + bcol
                                     : (lane < 32 ? counts.cb : counts.cr) + (size_t)ty * bw_c + bcol;
-                *dst = (uint8_t)count_pairs(w);
+                if (valid)
+                    *dst = (uint8_t)count_pairs(w);
             }
         }
         wave_lds_fence();
@@ -645,7 +769,11 @@ Transform transform_choice()
         return Transform::mfma_f32;
     if (e && strcmp(e, "xdl") == 0)
         return Transform::xdl_f16;
+#ifdef JPEGAMD_DEFAULT_XDL
+    return Transform::xdl_f16;
+#else
     return Transform::valu;
+#endif
 }
 
 // JPEGAMD_GRID=pertile: one wave per tile (round 1); default: persistent waves (both fused kernels)
@@ -753,6 +881,14 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
         return 0;
     }
     const Transform tr = transform_choice();
+    if (tr == Transform::xdl_f16) { // the same kernel with its row pass on the 16-bit matrix pipe
+        const auto kern = &encode_image_kernel<false, false, 1>;
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop, 0, d_bgr, rows, cols,
+                              stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles,
+                              CountPlanes{nullptr, nullptr, nullptr});
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (tr != Transform::valu)
         // the f32 matrix-core variant takes one tile per wave (never the capped grid: it would leave the
         // tiles beyond 12 x CUs unwritten); the f16 row-pass variant loops over tiles like the kernel above

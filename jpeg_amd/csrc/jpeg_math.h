@@ -190,10 +190,14 @@ JM_HD void jm_inv_colour(int y, int cb, int cr, const JmChromaTerm &c, int &o0, 
 
 // LEVEL: subtract the 128 level shift (recenterAroundZero, :289-298) -- it only
 // reaches the u=0 output, every other output is built from differences.
-template <int SNUM, bool LEVEL>
+// LEVEL_SUM: what the level shift amounts to in (t0 + t1), the sum of the eight inputs: 8 * 128 for
+// pixels; the matrix-pipe row pass hands over row sums scaled by 2^-10 * a_0 and shifts them in the
+// column pass instead (jpeg_kernels.hip), where the sum of eight of them carries 8 * 128 * 8 a_0 / 1024.
+template <int SNUM, bool LEVEL, int LEVEL_SUM_NUM = 1024, int LEVEL_SUM_DEN = 1>
 JM_HD void jm_fdct8(float &x0, float &x1, float &x2, float &x3,
                     float &x4, float &x5, float &x6, float &x7)
 {
+    constexpr float LEVEL_SUM = (float)((double)LEVEL_SUM_NUM / (double)LEVEL_SUM_DEN);
     constexpr double S = (double)SNUM;
     constexpr float A0 = (float)(S * JM_A0), C1 = (float)(S * JM_C1), C2 = (float)(S * JM_C2),
                     C3 = (float)(S * JM_C3), C5 = (float)(S * JM_C5), C6 = (float)(S * JM_C6),
@@ -201,7 +205,7 @@ JM_HD void jm_fdct8(float &x0, float &x1, float &x2, float &x3,
     float s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
     float d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
     float t0 = s0 + s3, t1 = s1 + s2, t2 = s0 - s3, t3 = s1 - s2;
-    x0 = LEVEL ? A0 * ((t0 + t1) - 1024.0f) : A0 * (t0 + t1);
+    x0 = LEVEL ? A0 * ((t0 + t1) - LEVEL_SUM) : A0 * (t0 + t1);
     x4 = A0 * (t0 - t1);
     x2 = jm_fma(C2, t2, C6 * t3);
     x6 = jm_fma(C6, t2, -(C2 * t3));
