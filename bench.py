@@ -91,6 +91,21 @@ def cpu_baseline(bgr_crop, qy, qc):
     return res
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on file descriptor 1 when its first communicator comes up; the contract
+    is ONE JSON line on stdout, so the descriptor points at stderr while the process group is set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -175,14 +190,159 @@ def rle_variant(lib, _lib, torch, dev, stream, enc_args, coefs, rows, cols, iter
     if any(t > c for t, c in zip(totals, caps)):
         return {"error": "pair buffers too small for this image", "pairs": totals}
     npix = rows * cols
+    # Two ways to price the same launches: (a) what this chain actually has to move -- the encoder's
+    # 6 B/px plus one count byte per block, then the coefficient planes read back (3 B/px) and the pairs and
+    # offsets written; (b) SURVEY 8d's definition for an encoder that emits pairs INSTEAD of dense planes:
+    # 3 B/px in, 8 B per pair + 4 B per block out -- the dense planes and their re-read count as overhead.
     nbytes = 6.0 * npix + sum(nbs) + 3.0 * npix + 8.0 * sum(totals) + 4.0 * sum(nbs)
+    pair_only = 3.0 * npix + 8.0 * sum(totals) + 4.0 * sum(nbs)
     return {"workload": "fused encode + (value, run) pairs of the three planes (jpegamd_encode_image_rle_dev)",
             "ms": ms, "pairs": totals, "pairs_per_block": sum(totals) / sum(nbs),
             "algorithmic_bytes": nbytes, "GBs": nbytes / (ms * 1e-3) / 1e9,
             "frac_of_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_of_peak_counts": "dense coefficient planes written by the encoder AND re-read by the run-length kernels as algorithmic bytes",
+            "pair_emitting_bytes": pair_only,
+            "frac_of_peak_pair_emitting": pair_only / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_of_peak_pair_emitting_counts": "SURVEY 8d: 3 B/px in + 8 B/pair + 4 B/block out only (dense planes = overhead)",
             "Mpixel_s": npix / (ms * 1e-3) / 1e6,
             "timing": "median of per-call intervals between torch events on the launching stream (four kernels "
                       "and their launch gaps); per-kernel durations: profiles/"}
+
+
+def timed_variant(jpeg_amd, torch, bgr, qy, qc, iters, workload):
+    """encode + decode of one resident image (any rows x cols): per-kernel HIP-event times in sequence and
+    the wall clock of `iters` steps on the stream; never mixed into `value`."""
+    rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
+    coefs = jpeg_amd.encode_image(bgr, qy, qc)
+    rec = jpeg_amd.decode_image(*coefs, rows, cols, qy, qc)
+    jpeg_amd.time_image(bgr, coefs, rec, qy, qc, 3)
+    enc_ms, dec_ms = jpeg_amd.time_image(bgr, coefs, rec, qy, qc, iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        jpeg_amd.encode_image(bgr, qy, qc, out=coefs)
+        jpeg_amd.decode_image(*coefs, rows, cols, qy, qc, out=rec)
+    torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) / iters * 1e3
+    npix = rows * cols
+    mse = float(((bgr[:4096].float() - rec[:4096].float()) ** 2).mean().item())
+    return {"workload": workload, "pixels": npix, "encode_ms": enc_ms, "decode_ms": dec_ms, "ms_per_step": step_ms,
+            "Mpixel_s": npix / (step_ms * 1e-3) / 1e6,
+            "kernels_Mpixel_s": npix / ((enc_ms + dec_ms) * 1e-3) / 1e6,
+            "enc_plus_dec_frac_of_peak": (BYTES_PER_PIXEL_ENC + BYTES_PER_PIXEL_DEC) * npix
+                                         / ((enc_ms + dec_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roundtrip_mse_first_rows": mse}
+
+
+def run_strips(args):
+    """--mode strips (SURVEY.md 8e "single large image"; north_star: "partitioned across the 8 GPUs as
+    independent MCU-row strips ... RCCL only to gather encoded strips").  ONE size x size image; rank r owns
+    the MCU rows strip_rows(r) and per step runs the fused encoder + run-length stage on them
+    (jpegamd_encode_image_rle_dev), the three pair streams go to the writer (sizes by all_gather, streams
+    point to point: jpeg_amd.shard.gather_streams_to_writer), and the writer's device entropy stage makes the
+    ONE .bin (jpegamd_bin_encode_dev).  value = image pixels / max-over-ranks time per step; the sha256 of
+    the .bin is in the line and must be the same for every N."""
+    import hashlib
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import jpeg_amd
+    from jpeg_amd import _lib, shard
+    from jpeg_amd.synth import synth_image
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    shared = world > torch.cuda.device_count()
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    if "MASTER_ADDR" not in os.environ:  # N = 1 without a launcher: a world of one, so that the RCCL path runs
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    with _StdoutToStderr():
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.barrier()  # the first collective brings the communicator (and RCCL's banner) up
+    jpeg_amd.init(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+
+    rows = cols = args.size
+    qy, qc = jpeg_amd.quality_tables(args.quality)
+    r0, r1 = shard.strip_rows(rows, world, rank)
+    h = r1 - r0
+    strip = synth_image(h, cols, 0x8192, "photo", device=dev, row_offset=r0)  # this rank's rows of THE image
+    nbs = [(h // 8) * (cols // 8), (h // 16) * (cols // 16), (h // 16) * (cols // 16)]
+    coefs = [torch.empty((n, 64), dtype=torch.int16, device=dev) for n in nbs]
+    work = torch.empty(lib.jpegamd_rle_workspace_bytes(sum(nbs)) + 256, dtype=torch.uint8, device=dev)
+    wptr = (work.data_ptr() + 255) & ~255
+    offs = [torch.empty(n + 1, dtype=torch.int32, device=dev) for n in nbs]
+    caps = [n * 16 for n in nbs]
+    pairs = [torch.empty((c, 2), dtype=torch.int32, device=dev) for c in caps]
+    ql32, qc32 = (np.ascontiguousarray(np.asarray(t, np.int32).reshape(64)) for t in (qy, qc))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    arr = lambda vals, t: (t * 3)(*vals)
+    rle_args = (strip.data_ptr(), h, cols, cols * 3, ql32.ctypes.data, qc32.ctypes.data,
+                arr([c.data_ptr() for c in coefs], ctypes.c_void_p), arr([p.data_ptr() for p in pairs], ctypes.c_void_p),
+                arr(caps, ctypes.c_size_t), arr([o.data_ptr() for o in offs], ctypes.c_void_p), wptr, work.numel() - 256, stream)
+    gather_dev = "cpu" if shared else dev  # (a rehearsal on one GPU exchanges through gloo on host tensors)
+
+    def step():
+        if h:
+            _lib.check(lib.jpegamd_encode_image_rle_dev(*rle_args))
+            totals = torch.stack([o[n] for o, n in zip(offs, nbs)]).tolist()  # one small device-to-host read
+            if any(t > c for t, c in zip(totals, caps)):
+                raise SystemExit("strips: pair buffers too small for this image")
+            streams = [p[:t].to(gather_dev) for p, t in zip(pairs, totals)]
+        else:
+            streams = [torch.empty((0, 2), dtype=torch.int32, device=gather_dev) for _ in range(3)]
+        whole = shard.gather_streams_to_writer(streams, None, 0)
+        if whole is None:
+            return None
+        return jpeg_amd.bin_encode_dev(*(w.to(dev) for w in whole), rows, cols)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    data = None
+    for _ in range(max(1, args.warmup)):
+        data = step()
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            data = step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if shared else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions.append(float(t.item()))
+    dt = sorted(regions)[len(regions) // 2]
+    if rank == 0:
+        npix = rows * cols
+        line = {
+            "metric": "single-image strip-sharded compress Mpixel/s (image -> one .bin)",
+            "value": npix * args.steps / dt / 1e6, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "timed_regions_ms": [round(x * 1e3, 4) for x in regions], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ONE synthetic {rows}x{cols} RGB image QF={args.quality}, MCU-row strips over the ranks: fused "
+                                   f"encode + run-length pairs per strip, pair streams gathered to the writer, device entropy "
+                                   f"stage, one .bin", "mode": "strips",
+                       "parallelism": f"strips x{world}" + (", REHEARSAL: ranks share one GPU, exchange over gloo" if shared else
+                                                            ", exchange over RCCL (sizes all_gather, streams send/recv)")},
+            "bin_bytes": len(data), "bin_sha256": hashlib.sha256(data).hexdigest(),
+            "note": "whole-path figure with host synchronisation per step (stream sizes are read on the host); the "
+                    "headline metric is the default mode's",
+        }
+        print(json.dumps(line), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -196,6 +356,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the worst-case input and the run-length variant (a profile of the two fused kernels alone)")
+    ap.add_argument("--mode", choices=("batch", "strips"), default="batch",
+                    help="batch (default, the headline): whole images per rank; strips: ONE image sharded by MCU-row strips, "
+                         "encoded strips gathered to the writer, one .bin")
     args = ap.parse_args()
 
     # --gpus N > 1 with no launcher around this process (no WORLD_SIZE): start the N ranks
@@ -203,6 +366,9 @@ def main():
     # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks exist already.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(run_as_launcher(args.gpus, sys.argv[1:]))
+
+    if args.mode == "strips":
+        return run_strips(args)
 
     import torch
     import jpeg_amd
@@ -221,10 +387,12 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        with _StdoutToStderr():
+            if shared:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()  # the first collective brings the communicator (and RCCL's banner) up
     else:
         dist = None
     jpeg_amd.init(local)
@@ -311,6 +479,32 @@ def main():
     if world == 1 and not args.headline_only:
         rle = rle_variant(lib, _lib, torch, dev, stream, enc_args, coefs, rows, cols, max(10, args.steps))
 
+    # north_star: "reported on synthetic and Lena-derived images ... and on 4K image batches".  Two more inputs,
+    # each an object of its own in the line, never part of `value`:
+    #   batch_variant  one GPU's share of BASELINE configs[3] (512 images of 3840x2160 over 8 GPUs = 64 per GPU) as ONE
+    #                  tall image: MCU rows are independent, so a contiguous batch is one launch
+    #   lena_variant   the Lena photograph x8 (integer bilinear, jpeg_amd.synth.lena_upscaled) = 8192^2: a photograph
+    #                  has few exact colour ties (its G and B rarely coincide), the synthetic fields many
+    batch = lena = None
+    if world == 1 and not args.headline_only and args.size == 8192:
+        from jpeg_amd.synth import lena_upscaled
+        n_img, b_rows, b_cols = 64, 2160, 3840
+        tall = torch.empty((n_img * b_rows, b_cols, 3), dtype=torch.uint8, device=dev)
+        for i in range(n_img):
+            tall[i * b_rows:(i + 1) * b_rows] = synth_image(b_rows, b_cols, i, "photo", device=dev)
+        batch = timed_variant(jpeg_amd, torch, tall, qy, qc, 10,
+                              f"{n_img} synthetic {b_cols}x{b_rows} RGB images QF={args.quality} (seeds 0..{n_img - 1}) resident in HBM, "
+                              f"one encode + one decode launch for the batch (one GPU's share of BASELINE configs[3])")
+        batch["images"] = n_img
+        del tall
+        try:
+            photo = lena_upscaled(8, device=dev)
+            lena = timed_variant(jpeg_amd, torch, photo, qy, qc, max(10, args.steps),
+                                 f"Lena 1024^2 x8 integer bilinear = 8192x8192 RGB QF={args.quality} (Lena-derived, SURVEY 8d)")
+            del photo
+        except OSError as e:  # the committed golden input travels with the repo; say so if it does not
+            lena = {"error": f"Lena input not found: {e}"}
+
     if rank == 0:
         dominant = "encode_image_kernel" if enc_ms >= dec_ms else "decode_image_kernel"
         ach = enc_gbs if enc_ms >= dec_ms else dec_gbs
@@ -347,6 +541,12 @@ def main():
             line["worst_case_input"] = worst
         if rle is not None:
             line["rle_variant"] = rle
+        if batch is not None:
+            line["batch_variant"] = batch
+        if lena is not None:
+            line["lena_variant"] = lena
+        if world > 1:
+            line["omitted_at_n_gt_1"] = ["cpu_baseline", "rle_variant", "worst_case_input", "batch_variant", "lena_variant"]
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N=1 figure
             # bounded sample: about 20 s of single-thread oracle work = one whole 8192^2 image
             crop_r, crop_c = min(rows, 8192), min(cols, 8192)

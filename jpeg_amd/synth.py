@@ -31,9 +31,10 @@ def _octave(yy, xx, c, seed, cell):
     return ((cell - fy) * top + fy * bot) // (cell * cell)
 
 
-def synth_image(rows, cols, seed=0, kind="photo", device="cpu"):
-    """uint8 tensor [rows, cols, 3] in cv::imread channel order."""
-    yy = torch.arange(rows, dtype=torch.int64, device=device).view(rows, 1)
+def synth_image(rows, cols, seed=0, kind="photo", device="cpu", row_offset=0):
+    """uint8 tensor [rows, cols, 3] in cv::imread channel order.  row_offset: generate rows
+    [row_offset, row_offset + rows) of a taller image of the same seed (a rank's MCU-row strip)."""
+    yy = torch.arange(row_offset, row_offset + rows, dtype=torch.int64, device=device).view(rows, 1)
     xx = torch.arange(cols, dtype=torch.int64, device=device).view(1, cols)
     out = torch.empty((rows, cols, 3), dtype=torch.uint8, device=device)
     for c in range(3):

@@ -209,3 +209,60 @@ def test_virtual_ranks_encoded_strips_give_the_single_gpu_bin(gpu):
                     streams[k].append(pairs)
         data = jpeg_amd.bin_encode_dev(*(torch.cat(s) for s in streams), rows, cols)
         assert data == want, world
+
+
+@pytest.mark.gpu
+def test_compress_image_sharded_over_rccl_world_of_one(gpu, lena_bgr):
+    """compress_image_sharded had never run on the `nccl` backend.  A world of ONE rank
+    on the one GPU executes exactly the calls the 8-GPU run makes -- init over RCCL, all_gather of
+    device tensors for the stream sizes, the writer's concatenation and device entropy stage (only the
+    send/recv pairs need a second rank; gloo world-2/3 above cover those).  The file must be the
+    single-call one and, for Lena, the reference's committed golden .bin."""
+    import hashlib
+    import torch.distributed as dist
+    import jpeg_amd
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0,
+                            device_id=gpu)
+    try:
+        qy, qc = jpeg_amd.quality_tables(50)
+        data = shard.compress_image_sharded(torch.from_numpy(lena_bgr).to(gpu), 1024, 1024, qy, qc)
+        assert hashlib.sha256(data).hexdigest() == "7870d3fec500635c7ef9dc5a98f985f31dbb2c91b0beb8d0c6ba9f9dbf82b2bf"
+        rows, cols = 528, 1040
+        img = synth_image(rows, cols, 13, "photo", device=gpu)
+        assert shard.compress_image_sharded(img, rows, cols, qy, qc) == jpeg_amd.compress_image(img.cpu().numpy(), qy, qc)
+        # the dense-plane exchange of the decode direction on the same backend
+        whole = jpeg_amd.encode_image(img, qy, qc)
+        mine = shard.scatter_planes_from_writer(list(whole), rows, cols, device=gpu)
+        assert all(torch.equal(a, b) for a, b in zip(mine, whole))
+        t = torch.ones(3, device=gpu)
+        dist.all_reduce(t)  # and one plain RCCL collective on device memory
+        assert t.tolist() == [1.0, 1.0, 1.0]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_strips_mode_gives_the_same_bin_for_one_and_two_ranks(gpu):
+    """bench.py --mode strips: ONE image, MCU-row strips over the ranks, encoded strips gathered to the
+    writer, one .bin.  N = 1 runs over RCCL (a world of one); N = 2 on this one-GPU box is the rehearsal
+    (ranks share the GPU, exchange over gloo).  Same sha256, and the same as compress_image of the image."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    import jpeg_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    lines = []
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "strips", "--gpus", str(n), "--size", "1024",
+                            "--steps", "2", "--warmup", "1", "--repeats", "1"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert lines[0]["n_gpus"] == 1 and lines[1]["n_gpus"] == 2 and "REHEARSAL" in lines[1]["config"]["parallelism"]
+    assert lines[0]["bin_sha256"] == lines[1]["bin_sha256"]
+    qy, qc = jpeg_amd.quality_tables(50)
+    want = jpeg_amd.compress_image(synth_image(1024, 1024, 0x8192, "photo").numpy(), qy, qc)
+    assert lines[0]["bin_sha256"] == hashlib.sha256(want).hexdigest() and lines[0]["bin_bytes"] == len(want)
