@@ -143,7 +143,10 @@ int jpegamd_encode_image_rle_dev(const uint8_t *d_bgr, int rows, int cols, size_
  * 16384 x 16384 plane); larger planes are rejected with an error.  All calls on one GPU share
  * that array: calls that overlap on one GPU (different streams or threads) race -- serialise
  * them.  Nothing in the array needs to start at zero (every word read was written by the same
- * call first). */
+ * call first).  UNDER STREAM CAPTURE call jpegamd_init(device) (or make one un-captured call on
+ * that device) FIRST: the array's address on a device is looked up once per device with
+ * hipGetSymbolAddress, which must not run inside a capture; a call that finds the address not yet
+ * looked up while `stream` is capturing returns an error instead of looking it up. */
 int jpegamd_rle_encode_plane_noalloc_dev(const int16_t *d_coef_zz, size_t nb, int32_t *d_pairs, size_t cap_pairs,
                                          uint32_t *d_block_offsets, void *stream);
 size_t jpegamd_rle_noalloc_max_blocks(void);

@@ -92,6 +92,8 @@ def encode_image(bgr, q_luma, q_chroma, out=None, stream=None):
     """bgr: cuda uint8 [rows, cols, 3] -> (coef_y, coef_cb, coef_cr) cuda int16
     [blocks, 64] in zigzag order (jpegamd_encode_image_dev)."""
     import torch
+    if bgr.dim() != 3 or int(bgr.shape[2]) != 3:
+        raise ValueError("encode_image: expected a [rows, cols, 3] image")
     rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
     ny, nc = _plane_sizes(rows, cols)
     src = _dev(bgr, torch.uint8, "encode_image", rows * cols * 3)
@@ -110,8 +112,11 @@ def colour_planes(bgr, stream=None):
     """RGB2YCbCr + chromaSubsampling (encode_decode.cpp:39-75, 117-152) through the fused
     encoder's colour stage: cuda uint8 [rows, cols, 3] -> (Y [rows, cols], Cb, Cr [rows/2, cols/2])."""
     import torch
+    if bgr.dim() != 3 or int(bgr.shape[2]) != 3:
+        raise ValueError("colour_planes: expected a [rows, cols, 3] image")
     rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
-    src = _dev(bgr, torch.uint8, "colour_planes")
+    _plane_sizes(rows, cols)
+    src = _dev(bgr, torch.uint8, "colour_planes", rows * cols * 3)
     y = torch.empty((rows, cols), dtype=torch.uint8, device=bgr.device)
     cb = torch.empty((rows // 2, cols // 2), dtype=torch.uint8, device=bgr.device)
     cr = torch.empty_like(cb)
@@ -242,7 +247,7 @@ def rle_encode_planes(coefs, stream=None):
     if len(coefs) not in (1, 3):
         raise ValueError("rle_encode_planes: one plane or three")
     nbs = [int(c.shape[0]) for c in coefs]
-    srcs = [_dev(c, torch.int16, "rle_encode_planes") for c in coefs]
+    srcs = [_dev(c, torch.int16, "rle_encode_planes", nb * 64) for c, nb in zip(coefs, nbs)]
     dev = coefs[0].device
     work = torch.empty(lib.jpegamd_rle_workspace_bytes(sum(nbs)), dtype=torch.uint8, device=dev)
     offs = [torch.empty(nb + 1, dtype=torch.int32, device=dev) for nb in nbs]
@@ -272,8 +277,11 @@ def encode_image_rle(bgr, q_luma, q_chroma, stream=None):
     ((coef_y, coef_cb, coef_cr), [(pairs, block_offsets)] * 3)."""
     import torch
     lib = _lib.load()
+    if bgr.dim() != 3 or int(bgr.shape[2]) != 3:
+        raise ValueError("encode_image_rle: expected a [rows, cols, 3] image")
     rows, cols = int(bgr.shape[0]), int(bgr.shape[1])
-    src = _dev(bgr, torch.uint8, "encode_image_rle")
+    _plane_sizes(rows, cols)
+    src = _dev(bgr, torch.uint8, "encode_image_rle", rows * cols * 3)
     dev = bgr.device
     nbs = [(rows // 8) * (cols // 8)] + [(rows // 16) * (cols // 16)] * 2
     coefs = tuple(torch.empty((n, 64), dtype=torch.int16, device=dev) for n in nbs)

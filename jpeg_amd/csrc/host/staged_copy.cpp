@@ -152,7 +152,7 @@ private:
     }
 };
 
-constexpr int kMaxDevices = 16; // more GPUs than any node of this kind has
+constexpr int kMaxDevices = kJpegamdMaxDevices; // host_common.h
 StagedCopier g_copiers[kMaxDevices];
 
 StagedCopier *copier_of_current_device()

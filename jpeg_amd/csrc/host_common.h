@@ -6,6 +6,9 @@
 #include <cstddef>
 #include <cstdint>
 
+// device indices the library keeps per-device state for (copier, scratch address, CU count): one limit for all of it
+constexpr int kJpegamdMaxDevices = 64;
+
 // stores the message for jpegamd_last_error() (thread-local) and returns 1
 __attribute__((visibility("hidden"), format(printf, 1, 2))) int jpegamd_fail(const char *fmt, ...);
 

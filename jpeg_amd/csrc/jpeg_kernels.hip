@@ -799,11 +799,11 @@ static thread_local char g_err[512] = "";
 // compute units of the current device (cached per device)
 int jpegamd_cu_count(int *out)
 {
-    static int cached[64];
+    static int cached[kJpegamdMaxDevices];
     int dev = -1;
     JPEGAMD_HIPCHK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64)
-        return jpegamd_fail("device %d beyond the 64 this library knows", dev);
+    if (dev < 0 || dev >= kJpegamdMaxDevices)
+        return jpegamd_fail("device %d beyond the %d this library knows", dev, kJpegamdMaxDevices);
     int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
     if (!n) {
         JPEGAMD_HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));

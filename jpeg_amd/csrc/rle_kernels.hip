@@ -11,10 +11,15 @@
 // std::vector<int>, so the host entropy coder can consume the copied-back
 // buffer as is.  All of it is integer work and bit-exact.
 //
-// Encoding is ONE pass (rle_encode_kernel: counts chained between workgroups).  A wave stages 64
-// consecutive blocks through LDS (coalesced 16 B per lane in, one block per lane
-// out, the same 144-B pitch as the transform kernels) and a lane walks its own
-// block in registers.  HBM-bound: 2 B/coefficient read + 8 B/pair written.
+// Encoding is pairs per tile of 256 blocks -> exclusive scan -> emit (three launches for up to three
+// planes).  The per-block pair counts come from the fused encoder (one byte per block, summed by
+// rle_tile_sums_kernel: the coefficients are then read ONCE, by the emit kernel) or, for planes from
+// anywhere else, from rle_count_kernel (a second read).  In the emit kernel a wave stages 64
+// consecutive blocks through LDS (coalesced 16 B per lane in, one block per lane out, the same
+// 144-B pitch as the transform kernels), a lane walks the run ends of its own block, and the wave's
+// pairs leave through LDS as contiguous 8-byte stores.  HBM-bound: 2 B/coefficient read (+ 1 B per
+// block of counts) + 8 B/pair + 4 B/block written.  (A single pass with the counts chained between
+// workgroups was measured and dropped: see below.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -30,7 +35,7 @@ namespace {
 constexpr int kPitch = 144;          // staged block pitch (128 + 16: conflict-free b128)
 constexpr int kBlocksPerWg = 256;    // 4 waves x 64 blocks
 constexpr int kPairsPerWg = 1024;    // decode: 256 threads x 4 pairs
-constexpr int kMaxDevices = 64;
+constexpr int kMaxDevices = kJpegamdMaxDevices; // host_common.h
 
 __device__ __forceinline__ void wave_fence()
 {
@@ -449,20 +454,31 @@ namespace {
 std::mutex g_scratch_mu;
 uint32_t *g_scratch_ptr[kMaxDevices]; // device address of `scratch` on each device, once looked up
 
-int noalloc_scratch_for_current_device(uint32_t **out)
+int noalloc_scratch_for_current_device(uint32_t **out, hipStream_t stream = nullptr, bool check_capture = false)
 {
     int dev = -1;
     JPEGAMD_HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices)
         return jpegamd_fail("rle_encode_plane_noalloc: device %d beyond the %d this library keeps scratch for", dev,
                             kMaxDevices);
+    // the common case takes no lock: the address never changes once it is there
+    if (uint32_t *p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE)) {
+        *out = p;
+        return 0;
+    }
+    if (check_capture) { // a symbol lookup inside a stream capture would break or invalidate the capture
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+            return jpegamd_fail("rle_encode_plane_noalloc: device %d has not been set up and the stream is capturing; call "
+                                "jpegamd_init(%d) (or one un-captured call) before capturing", dev, dev);
+    }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
         void *p = nullptr;
         JPEGAMD_HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         if (!p)
             return jpegamd_fail("rle_encode_plane_noalloc: hipGetSymbolAddress returned a null address");
-        g_scratch_ptr[dev] = static_cast<uint32_t *>(p);
+        __atomic_store_n(&g_scratch_ptr[dev], static_cast<uint32_t *>(p), __ATOMIC_RELEASE);
     }
     *out = g_scratch_ptr[dev];
     return 0;
@@ -553,7 +569,7 @@ int jpegamd_rle_encode_plane_noalloc_dev(const int16_t *d_coef_zz, size_t nb, in
         return jpegamd_fail("rle_encode_plane_noalloc: nb=%zu exceeds the built-in scratch (%zu blocks); use "
                             "jpegamd_rle_encode_plane_dev with a workspace", nb, kNoAllocMaxBlocks);
     uint32_t *work = nullptr;
-    if (noalloc_scratch_for_current_device(&work))
+    if (noalloc_scratch_for_current_device(&work, static_cast<hipStream_t>(stream), true))
         return 1;
     const RlePlane pl{d_coef_zz, d_block_offsets, reinterpret_cast<int2 *>(d_pairs), cap_pairs, nullptr, (uint32_t)nb, 0};
     return launch_rle_encode(&pl, 1, work, static_cast<hipStream_t>(stream));
