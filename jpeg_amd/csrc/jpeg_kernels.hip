@@ -847,6 +847,9 @@ int jpegamd_init(int device)
     // pinned staging buffers and streams
     if (jpegamd_rle_noalloc_setup()) // this device's address of the no-alloc entry point's scratch
         return 1;
+    int cus = 0;
+    if (jpegamd_cu_count(&cus)) // cached per device: the persistent grids are sized by it
+        return 1;
     return jpegamd_staged_copy_warm();
 }
 

@@ -11,8 +11,8 @@
 // std::vector<int>, so the host entropy coder can consume the copied-back
 // buffer as is.  All of it is integer work and bit-exact.
 //
-// Encoding is pairs per tile of 256 blocks -> exclusive scan -> emit (three launches for up to three
-// planes).  The per-block pair counts come from the fused encoder (one byte per block, summed by
+// Encoding is pairs per tile of 256 blocks -> emit (two launches for up to three planes; the emit
+// kernel adds up the tiles before its own: the separate scan of round 2 is gone).  The per-block pair counts come from the fused encoder (one byte per block, summed by
 // rle_tile_sums_kernel: the coefficients are then read ONCE, by the emit kernel) or, for planes from
 // anywhere else, from rle_count_kernel (a second read).  In the emit kernel a wave stages 64
 // consecutive blocks through LDS (coalesced 16 B per lane in, one block per lane out, the same
@@ -87,7 +87,7 @@ typedef unsigned long long u64;
 // ---- run_length_encode ----------------------------------------------------------------
 // A tile is 256 consecutive blocks of a plane (one workgroup, one block per lane).  To place a
 // tile's pairs the number of pairs of all blocks before it is needed (the stream is the
-// blocks' pairs in raster order, :643-645): pairs per tile -> exclusive scan -> emit.
+// blocks' pairs in raster order, :643-645): pairs per tile -> emit (which sums the tiles before its own).
 // Where the per-block pair counts come from:
 //   * jpegamd_encode_image_rle_dev: from the fused ENCODER, whose lane holds the block's 64
 //     quantised values in registers anyway and writes one count byte per block; the tile sums
@@ -182,103 +182,144 @@ __global__ __launch_bounds__(256) void rle_tile_sums_kernel(RleJob job, uint32_t
     sums[tile] = t;
 }
 
-// exclusive scan of the tile sums in place, plane by plane, by ONE workgroup; each plane's total
-// goes to its block_offsets[nb]
-__global__ __launch_bounds__(1024) void rle_scan_kernel(RleJob job, uint32_t *__restrict__ sums)
+// per-block offsets and the pairs themselves; sums[tile] = pairs of tile `tile` (each workgroup adds up what lies before its tile).
+// PERSISTENT since round 3: the host launches no more workgroups than are resident at once, a
+// workgroup takes tiles blockIdx.x, + gridDim.x, ... and the 8 KiB of the NEXT tile's coefficients
+// are already on their way (eight 16-byte loads per lane in registers) while the current tile's run
+// ends are walked -- a wave of the one-tile-per-workgroup form lived 7.8 us for 0.9 us of instruction
+// issue (profiles/r03_d_pmc_rle_entropy_kernels.txt: 12.7 M VALU, 24 576 waves, 114.5 M wave cycles x 4):
+// launch, first fetch and the walk's LDS round trips one after the other.
+__device__ __forceinline__ void fetch_blocks(const RleJob &job, uint32_t tile, int wave, int lane, uint4 (&d)[8])
 {
-    __shared__ uint32_t wave_sums[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t pi = 0; pi < job.n_planes; ++pi) {
-        const uint32_t t0 = job.p[pi].tile_begin;
-        const uint32_t t1 = pi + 1 < job.n_planes ? job.p[pi + 1].tile_begin : job.n_tiles;
-        uint32_t carry = 0;
-        for (uint32_t base = t0; base < t1; base += 1024) { // uniform trip count
-            const uint32_t i = base + threadIdx.x;
-            const uint32_t x = i < t1 ? sums[i] : 0u;
-            const uint32_t inc = wave_inclusive_scan(x, lane);
-            if (lane == 63)
-                wave_sums[wave] = inc;
-            __syncthreads();
-            uint32_t before = 0, all = 0;
+    const RlePlane &pl = plane_of_tile(job, tile);
+    const size_t blk0 = (size_t)(tile - pl.tile_begin) * kBlocksPerWg + wave * 64;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(pl.coef + blk0 * 64);
+    const size_t n_ok = pl.nb > blk0 ? pl.nb - blk0 : 0;
+    const int blk = lane >> 3;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t t = wave_sums[k];
-                before += k < wave ? t : 0u;
-                all += t;
-            }
-            __syncthreads();
-            if (i < t1)
-                sums[i] = carry + before + inc - x;
-            carry += all;
-        }
-        if (threadIdx.x == 0)
-            job.p[pi].block_offsets[job.p[pi].nb] = carry;
+    for (int k = 0; k < 8; ++k) {
+        d[k] = make_uint4(0, 0, 0, 0);
+        if ((size_t)(k * 8 + blk) < n_ok)
+            d[k] = *reinterpret_cast<const uint4 *>(src + k * 1024 + lane * 16);
     }
 }
 
-// per-block offsets and the pairs themselves; sums[tile] = index of the tile's first pair
 __global__ __launch_bounds__(256) void rle_emit_kernel(RleJob job, const uint32_t *__restrict__ sums)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 64 * kPitch];
     __shared__ __attribute__((aligned(16))) int2 pair_stage[4][kPairStage];
-    __shared__ uint32_t wave_sums[4];
+    __shared__ uint32_t wave_sums[2][4], base_parts[2][4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = blockIdx.x;
-    const RlePlane &pl = plane_of_tile(job, tile);
-    const size_t blk0 = (size_t)(tile - pl.tile_begin) * kBlocksPerWg + wave * 64;
     uint8_t *stage = lds + wave * 64 * kPitch;
-    uint32_t w[32];
-    stage_blocks(pl.coef, blk0, pl.nb, stage, lane, w);
-    const uint32_t tile_base = sums[tile];
-    const bool valid = blk0 + lane < pl.nb;
-    unsigned long long ends = valid ? run_ends(w) : 0u;
-    const uint32_t n = (uint32_t)__builtin_popcountll(ends);
-    const uint32_t inc = wave_inclusive_scan(n, lane);
-    const uint32_t wave_total = __shfl(inc, 63, 64);
-    if (lane == 63)
-        wave_sums[wave] = inc;
-    __syncthreads();
-    uint32_t wave_base = tile_base;
+    uint32_t tile = blockIdx.x;
+    if (tile >= job.n_tiles)
+        return;
+    uint4 pre[8];
+    fetch_blocks(job, tile, wave, lane, pre);
+    uint32_t prev_tile = 0, prev_base = 0;
+    for (int round = 0;; ++round) {
+        const RlePlane &pl = plane_of_tile(job, tile);
+        const size_t blk0 = (size_t)(tile - pl.tile_begin) * kBlocksPerWg + wave * 64;
+        // index of the tile's first pair = sum of the sums of the plane's tiles before it: every thread adds
+        // a strided share (at most 16 words of a 16 KiB array that stays in L2), the four waves' shares meet
+        // in LDS at the barrier below.  This replaced rle_scan_kernel (one workgroup, 8 us, and a launch).
+        // (Only the tiles since this workgroup's previous tile are new when both lie in one plane.)
+        const bool same_plane = round > 0 && prev_tile >= pl.tile_begin;
+        const uint32_t from = same_plane ? prev_tile : pl.tile_begin;
+        const uint32_t base_before = same_plane ? prev_base : 0u;
+        uint32_t part = 0;
+        for (uint32_t t = from + threadIdx.x; t < tile; t += 256)
+            part += sums[t];
+        // staged: 64 blocks x 128 B at the 144-B pitch, then the lane's own block into registers
+        {
+            uint8_t *sp = stage + (lane >> 3) * kPitch + (lane & 7) * 16;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        wave_base += k < wave ? wave_sums[k] : 0u;
-    // one step per PAIR, not per value: the next set bit of `ends` is where the next run ends,
-    // its value is still in the lane's staged block (LDS), its length the distance to the
-    // previous end.  A wave takes as many steps as its busiest block has pairs.
-    const size_t wave_off = wave_base; // plane-wide index of the wave's first pair
-    const uint32_t lane_off = inc - n;
-    if (valid)
-        pl.block_offsets[blk0 + lane] = (uint32_t)(wave_off + lane_off);
-    const int16_t *own = reinterpret_cast<const int16_t *>(stage + lane * kPitch);
-    int prev = -1;
-    if (wave_total <= (uint32_t)kPairStage) {
-        // the wave's pairs are contiguous in the stream: collect them in LDS and store them 64 at
-        // a time, 512 contiguous bytes per instruction
-        int2 *ps = pair_stage[wave] + lane_off;
-        while (ends) {
-            const int pos = __builtin_ctzll(ends);
-            ends &= ends - 1;
-            *ps++ = make_int2((int)own[pos], pos - prev);
-            prev = pos;
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<uint4 *>(sp + k * 8 * kPitch) = pre[k];
         }
+        const uint32_t next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < job.n_tiles;
+        if (has_next) // in flight during everything below
+            fetch_blocks(job, next_tile, wave, lane, pre);
         wave_fence();
-        for (uint32_t i = lane; i < wave_total; i += 64)
-            if (wave_off + i < pl.cap_pairs)
-                pl.pairs[wave_off + i] = pair_stage[wave][i];
-    } else {
-        const size_t off = wave_off + lane_off;
-        int2 *__restrict__ out = pl.pairs + off;
-        const size_t room = off < pl.cap_pairs ? pl.cap_pairs - off : 0;
-        uint32_t j = 0;
-        while (ends) {
-            const int pos = __builtin_ctzll(ends);
-            ends &= ends - 1;
-            if (j < room)
-                out[j] = make_int2((int)own[pos], pos - prev);
-            ++j;
-            prev = pos;
+        uint32_t w[32];
+        const uint4 *mine = reinterpret_cast<const uint4 *>(stage + lane * kPitch);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint4 d = mine[k];
+            w[4 * k] = d.x, w[4 * k + 1] = d.y, w[4 * k + 2] = d.z, w[4 * k + 3] = d.w;
         }
+        const bool valid = blk0 + lane < pl.nb;
+        unsigned long long ends = valid ? run_ends(w) : 0u;
+        const uint32_t n = (uint32_t)__builtin_popcountll(ends);
+        const uint32_t inc = wave_inclusive_scan(n, lane);
+        const uint32_t wave_total = __shfl(inc, 63, 64);
+        part = wave_sum32(part);
+        if (lane == 63) { // (two sets: a fast wave's next round must not overwrite this one's)
+            wave_sums[round & 1][wave] = inc;
+            base_parts[round & 1][wave] = part;
+        }
+        __syncthreads();
+        uint32_t wave_base = base_before + base_parts[round & 1][0] + base_parts[round & 1][1] + base_parts[round & 1][2] +
+                             base_parts[round & 1][3];
+        prev_tile = tile, prev_base = wave_base; // (the tile's own base, before the waves' shares are added)
+        if (threadIdx.x == 0 && blk0 + kBlocksPerWg >= pl.nb) // the plane's last tile: its end is the plane's total
+            pl.block_offsets[pl.nb] = wave_base + wave_sums[round & 1][0] + wave_sums[round & 1][1] +
+                                      wave_sums[round & 1][2] + wave_sums[round & 1][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            wave_base += k < wave ? wave_sums[round & 1][k] : 0u;
+        // one step per PAIR, not per value: the next set bit of `ends` is where the next run ends,
+        // its value is still in the lane's staged block (LDS), its length the distance to the
+        // previous end.  A wave takes as many steps as its busiest block has pairs; the value of
+        // step i + 1 is fetched before the pair of step i is written, so one LDS round trip, not
+        // two, separates the steps.
+        const size_t wave_off = wave_base; // plane-wide index of the wave's first pair
+        const uint32_t lane_off = inc - n;
+        if (valid)
+            pl.block_offsets[blk0 + lane] = (uint32_t)(wave_off + lane_off);
+        const int16_t *own = reinterpret_cast<const int16_t *>(stage + lane * kPitch);
+        int prev = -1;
+        if (wave_total <= (uint32_t)kPairStage) {
+            // the wave's pairs are contiguous in the stream: collect them in LDS and store them 64 at
+            // a time, 512 contiguous bytes per instruction
+            int2 *ps = pair_stage[wave] + lane_off;
+            if (ends) {
+                int pos = __builtin_ctzll(ends);
+                ends &= ends - 1;
+                int val = own[pos];
+                while (ends) {
+                    const int npos = __builtin_ctzll(ends);
+                    ends &= ends - 1;
+                    const int nval = own[npos];
+                    *ps++ = make_int2(val, pos - prev);
+                    prev = pos, pos = npos, val = nval;
+                }
+                *ps = make_int2(val, pos - prev);
+            }
+            wave_fence();
+            for (uint32_t i = lane; i < wave_total; i += 64)
+                if (wave_off + i < pl.cap_pairs)
+                    pl.pairs[wave_off + i] = pair_stage[wave][i];
+        } else {
+            const size_t off = wave_off + lane_off;
+            int2 *__restrict__ out = pl.pairs + off;
+            const size_t room = off < pl.cap_pairs ? pl.cap_pairs - off : 0;
+            uint32_t j = 0;
+            while (ends) {
+                const int pos = __builtin_ctzll(ends);
+                ends &= ends - 1;
+                if (j < room)
+                    out[j] = make_int2((int)own[pos], pos - prev);
+                ++j;
+                prev = pos;
+            }
+        }
+        if (!has_next)
+            break;
+        wave_fence(); // the staged blocks and pairs are consumed (in-order LDS) before the next round overwrites them
+        tile = next_tile;
     }
 }
 
@@ -430,8 +471,12 @@ int launch_rle_encode(const RlePlane *planes, int n_planes, uint32_t *sums, hipS
         hipLaunchKernelGGL(rle_tile_sums_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, job, sums);
     else
         hipLaunchKernelGGL(rle_count_kernel, dim3(n_tiles), dim3(256), 0, s, job, sums);
-    hipLaunchKernelGGL(rle_scan_kernel, dim3(1), dim3(1024), 0, s, job, sums);
-    hipLaunchKernelGGL(rle_emit_kernel, dim3(n_tiles), dim3(256), 0, s, job, sums);
+    // persistent emit: no more workgroups than are resident at once (three per CU: 53 KB of LDS each)
+    int cus = 0;
+    if (jpegamd_cu_count(&cus))
+        return 1;
+    const uint32_t emit_grid = n_tiles < (uint32_t)(3 * cus) ? n_tiles : (uint32_t)(3 * cus);
+    hipLaunchKernelGGL(rle_emit_kernel, dim3(emit_grid), dim3(256), 0, s, job, sums);
     JPEGAMD_HIPCHK(hipGetLastError());
     return 0;
 }
