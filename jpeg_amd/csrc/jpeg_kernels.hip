@@ -80,6 +80,31 @@ constexpr RowPassTable make_row_pass_table()
 }
 __device__ const RowPassTable kRowPassTable = make_row_pass_table();
 
+#ifdef JPEGAMD_ROWPASS_A_FROM_MEMORY
+// experiment: the A operands are re-read from the table (L2) before every transform instead of being
+// held in 24 registers across the colour stage
+struct RowPassLane {
+    uint32_t off[2]; // byte offset of this lane's rows in kRowPassTable (or of the zero row), per v half
+};
+__device__ const RowPassTable kRowPassZero{};
+__device__ __forceinline__ RowPassLane make_row_pass_lane(int lane)
+{
+    RowPassLane k;
+    const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int vh = 0; vh < 2; ++vh)
+        k.off[vh] = (m >> 2) == g ? (uint32_t)((4 * vh + (m & 3)) * 16) : 0x80000000u;
+    return k;
+}
+__device__ __forceinline__ f16x8 row_pass_operand(const RowPassLane &k, int t, int vh)
+{
+    uint32_t off = k.off[vh];
+    asm volatile("" : "+v"(off)); // (not loop invariant for the compiler: it would hoist the loads and pin the registers again)
+    const uint8_t *base = (off & 0x80000000u) ? reinterpret_cast<const uint8_t *>(&kRowPassZero)
+                                              : reinterpret_cast<const uint8_t *>(&kRowPassTable) + off;
+    return *reinterpret_cast<const f16x8 *>(base + 128 * t);
+}
+#else
 struct RowPassLane {
     f16x8 a[3][2]; // A operands [term][v half]
 };
@@ -98,6 +123,8 @@ __device__ __forceinline__ RowPassLane make_row_pass_lane(int lane)
         }
     return k;
 }
+__device__ __forceinline__ f16x8 row_pass_operand(const RowPassLane &k, int t, int vh) { return k.a[t][vh]; }
+#endif
 
 // eight bytes -> eight f16 subnormals (byte * 2^-24)
 __device__ __forceinline__ f16x8 bytes_as_f16(uint2 raw)
@@ -120,6 +147,12 @@ __device__ __forceinline__ void rows_fdct_matrix_pipe(const uint8_t *src, int pi
     // the order 0, 7, 1, 6 | 2, 5, 3, 4, so that the column pass's first butterflies can be issued
     // under the second half's matrix instructions, measured no faster: profiles/r03_a_*.)
     constexpr int kOrder[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    f16x8 a[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int vh = 0; vh < 2; ++vh)
+            a[t][vh] = row_pass_operand(k, t, vh);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         f16x8 b[4];
@@ -133,7 +166,7 @@ __device__ __forceinline__ void rows_fdct_matrix_pipe(const uint8_t *src, int pi
             for (int y = 0; y < 4; ++y)
 #pragma unroll
                 for (int vh = 0; vh < 2; ++vh)
-                    acc[y][vh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.a[t][vh], b[y], t == 0 ? zero : acc[y][vh], 0, 0, 0);
+                    acc[y][vh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][vh], b[y], t == 0 ? zero : acc[y][vh], 0, 0, 0);
 #pragma unroll
         for (int y = 0; y < 4; ++y)
 #pragma unroll
