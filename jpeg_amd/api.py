@@ -366,23 +366,31 @@ def bin_decode(data):
 
 def bin_decode_dev(data, device="cuda:0"):
     """.bin bytes -> (dims[6], [sym_y, sym_cb, sym_cr] as cuda int32 tensors): huffman_decode on the
-    device (jpegamd_bin_decode_dev)."""
+    device (jpegamd_bin_decode_dev).  ONE call: the buffers are sized from the header -- a plane of nb
+    blocks holds at most 64 pairs per block (plus what up to 7 pad bits decode to) and no more symbols
+    than payload bits (what jpegamd_decompress_image does too); a file that decodes to more than that is
+    not an image of its header's size and gets the exact-size second call."""
     import torch
     lib = _lib.load()
     buf = np.frombuffer(data, np.uint8)
     dims = np.zeros(6, np.int32)
     n = (ctypes.c_size_t * 3)(0, 0, 0)
-    caps = [0, 0, 0]
-    syms = [None, None, None]
+    caps = [1, 1, 1]
+    if buf.size >= 36:
+        head = np.frombuffer(buf[:36].tobytes(), np.int32)
+        for k in range(3):
+            r, c, ln = int(head[2 * k]), int(head[2 * k + 1]), int(head[6 + k])
+            if 0 < r <= 1 << 20 and 0 < c <= 1 << 20 and ln >= 0:
+                caps[k] = max(1, min(((r + 7) // 8) * ((c + 7) // 8) * 128 + 16, ln * 8))
     for _ in range(2):
-        ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() if t is not None and t.numel() else None for t in syms])
+        syms = [torch.empty(c, dtype=torch.int32, device=device) for c in caps]
+        ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in syms])
         rc = lib.jpegamd_bin_decode_dev(buf.ctypes.data, buf.size, dims.ctypes.data, ptrs, (ctypes.c_size_t * 3)(*caps), n)
         if rc == 0:
             return dims, [t[:c] for t, c in zip(syms, n)]
-        if all(c <= cap and t is not None for c, cap, t in zip(n, caps, syms)):
+        if all(c <= cap for c, cap in zip(n, caps)):
             _lib.check(rc)
         caps = [max(int(c), 1) for c in n]
-        syms = [torch.empty(c, dtype=torch.int32, device=device) for c in caps]
     _lib.check(rc)
 
 

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "host/dev_alloc.h"
@@ -33,17 +34,25 @@ constexpr int kSubBits = 256; // bits per subsequence (one thread)
 constexpr int kThreads = 256;
 constexpr uint32_t kNoEnd = 0xFFFFFFFFu;
 
+// A plane's payload sits where the file has it: the three payloads are uploaded as ONE range (they are
+// contiguous in the .bin, encode_decode.cpp:1178-1186), so a plane begins at any byte of a word:
+// `words` is the word holding its first byte and bit0 = 8 x (the byte's place in that word).  Stream
+// positions are plane relative.  Bits read beyond the plane's end belong to whatever follows in the
+// buffer; every use of them is cut off by the bit count (a code is accepted only if it ends at or
+// before n_bits, and a prefix code's first `len` bits identify it whatever follows).
 struct Stream {
-    const uint32_t *words; // payload, zero padded to whole words plus two
-    uint32_t n_words;      // words that hold payload bytes
+    const uint32_t *words;
+    uint32_t n_words; // words that hold bytes of this plane
     uint32_t n_bits;
+    uint32_t bit0;
     const int32_t *left, *right, *value;
 };
 
-// 32 bits of the stream from bit `pos` on, MSB first; bits beyond the payload read as zero
+// 32 bits of the stream from bit `pos` on, MSB first
 __device__ __forceinline__ uint32_t peek32(const Stream &s, uint32_t pos)
 {
-    const uint32_t i = pos >> 5, sh = pos & 31;
+    const uint32_t q = pos + s.bit0;
+    const uint32_t i = q >> 5, sh = q & 31;
     const uint32_t hi = i < s.n_words ? __builtin_bswap32(s.words[i]) : 0u;
     const uint32_t lo = i + 1 < s.n_words ? __builtin_bswap32(s.words[i + 1]) : 0u;
     return (uint32_t)(((((unsigned long long)hi << 32) | lo) << sh) >> 32);
@@ -51,7 +60,28 @@ __device__ __forceinline__ uint32_t peek32(const Stream &s, uint32_t pos)
 
 __device__ __forceinline__ uint32_t bit_at(const Stream &s, uint32_t pos)
 {
-    return (__builtin_bswap32(s.words[pos >> 5]) >> (31 - (pos & 31))) & 1u;
+    const uint32_t q = pos + s.bit0;
+    return (__builtin_bswap32(s.words[q >> 5]) >> (31 - (q & 31))) & 1u;
+}
+
+// Up to three planes go through one launch of each kernel (round 3): a workgroup finds its plane from
+// the first workgroup index of each.
+struct HdPlane {
+    Stream s;
+    const uint32_t *window;
+    uint32_t n_sub, wg_begin;
+    uint32_t *sub_start, *sub_count, *ends_a, *ends_b;
+    uint32_t *changed;
+    unsigned long long *total;
+    int32_t *out;
+    size_t cap;
+};
+struct HdJob {
+    HdPlane p[3];
+};
+__device__ __forceinline__ const HdPlane &hd_plane_of(const HdJob &job, uint32_t wgid)
+{
+    return job.p[wgid >= job.p[2].wg_begin ? 2 : wgid >= job.p[1].wg_begin ? 1 : 0];
 }
 
 // Decodes codes from the boundary `pos` while pos < stop; returns the boundary reached (>= stop,
@@ -97,17 +127,21 @@ __device__ __forceinline__ uint32_t decode_range(const Stream &s, const uint32_t
 // wg_start_in[w] = the end the previous round found for workgroup w - 1's last subsequence; a
 // workgroup whose assumption was right already does nothing.  *changed is raised by any workgroup
 // that had to start again.
-__global__ __launch_bounds__(kThreads) void hd_sync_kernel(Stream s, const uint32_t *__restrict__ window,
-                                                           uint32_t n_sub, uint32_t *__restrict__ sub_start,
-                                                           uint32_t *__restrict__ sub_count,
-                                                           const uint32_t *__restrict__ wg_end_in,
-                                                           uint32_t *__restrict__ wg_end_out,
-                                                           uint32_t *__restrict__ changed)
+__global__ __launch_bounds__(kThreads) void hd_sync_kernel(HdJob job, int phase)
 {
     __shared__ uint32_t win[1 << kDecodeWindow];
     __shared__ uint32_t ends[kThreads];
     __shared__ int any;
-    const uint32_t wg = blockIdx.x, t = threadIdx.x;
+    const HdPlane &pl = hd_plane_of(job, blockIdx.x);
+    const Stream &s = pl.s;
+    const uint32_t *__restrict__ window = pl.window;
+    const uint32_t n_sub = pl.n_sub;
+    uint32_t *__restrict__ sub_start = pl.sub_start, *__restrict__ sub_count = pl.sub_count;
+    // phase 0: every workgroup assumes its own first bit, ends -> a; 1: a -> b; 2: b -> a
+    const uint32_t *__restrict__ wg_end_in = phase == 0 ? nullptr : phase == 1 ? pl.ends_a : pl.ends_b;
+    uint32_t *__restrict__ wg_end_out = phase == 1 ? pl.ends_b : pl.ends_a;
+    uint32_t *__restrict__ changed = pl.changed;
+    const uint32_t wg = blockIdx.x - pl.wg_begin, t = threadIdx.x;
     const uint32_t sub = wg * kThreads + t;
     const uint32_t first_bit = wg * kThreads * kSubBits;
     uint32_t wg_start = first_bit;
@@ -166,9 +200,13 @@ __global__ __launch_bounds__(kThreads) void hd_sync_kernel(Stream s, const uint3
 }
 
 // exclusive scan of n counts in place by ONE workgroup; the total goes to *total (64-bit)
-__global__ __launch_bounds__(1024) void hd_scan_kernel(uint32_t *__restrict__ v, uint32_t n,
-                                                       unsigned long long *__restrict__ total)
+__global__ __launch_bounds__(1024) void hd_scan_kernel(HdJob job)
 {
+    uint32_t *__restrict__ v = job.p[blockIdx.x].sub_count;
+    const uint32_t n = job.p[blockIdx.x].n_sub;
+    unsigned long long *__restrict__ total = job.p[blockIdx.x].total;
+    if (n == 0)
+        return; // (uniform: a plane that is not decoded here)
     // one workgroup, eight consecutive counts per thread and pass: a plane of 8192^2 has about
     // 110 000 subsequences, i.e. 14 passes
     constexpr uint32_t kPer = 8;
@@ -221,101 +259,217 @@ __global__ __launch_bounds__(1024) void hd_scan_kernel(uint32_t *__restrict__ v,
         *total = carry;
 }
 
-__global__ __launch_bounds__(kThreads) void hd_emit_kernel(Stream s, const uint32_t *__restrict__ window,
-                                                           uint32_t n_sub, const uint32_t *__restrict__ sub_start,
-                                                           const uint32_t *__restrict__ sub_offset,
-                                                           int32_t *__restrict__ out, size_t cap)
+__global__ __launch_bounds__(kThreads) void hd_emit_kernel(HdJob job)
 {
     __shared__ uint32_t win[1 << kDecodeWindow];
+    const HdPlane &pl = hd_plane_of(job, blockIdx.x);
     for (int i = threadIdx.x; i < (1 << kDecodeWindow); i += kThreads)
-        win[i] = window[i];
+        win[i] = pl.window[i];
     __syncthreads();
-    const uint32_t sub = blockIdx.x * kThreads + threadIdx.x;
-    if (sub >= n_sub)
+    const uint32_t sub = (blockIdx.x - pl.wg_begin) * kThreads + threadIdx.x;
+    if (sub >= pl.n_sub)
         return;
+    const Stream &s = pl.s;
     const uint32_t lo = sub * kSubBits;
     const uint32_t hi = lo + kSubBits < s.n_bits ? lo + kSubBits : s.n_bits;
-    const uint32_t start = sub_start[sub];
+    const uint32_t start = pl.sub_start[sub];
     uint32_t count;
     if (start < hi)
-        (void)decode_range<true>(s, win, start, hi, count, out, (size_t)sub_offset[sub], cap);
+        (void)decode_range<true>(s, win, start, hi, count, pl.out, (size_t)pl.sub_count[sub], pl.cap);
 }
 
 typedef JpegamdDevMem DevMem;
 
+// Pinned host scratch of the calling thread (tables up, status words back): grows, never shrinks, lives as
+// long as the thread.  Small asynchronous copies from and to it cost a queue entry each instead of the
+// staging and the wait of a pageable hipMemcpy.
+struct PinnedScratch {
+    void *p = nullptr;
+    size_t n = 0;
+    ~PinnedScratch()
+    {
+        if (p)
+            (void)hipHostFree(p);
+    }
+    void *ensure(size_t bytes)
+    {
+        if (n < bytes) {
+            if (p)
+                (void)hipHostFree(p);
+            p = nullptr, n = 0;
+            if (hipHostMalloc(&p, bytes + bytes / 4, hipHostMallocDefault) != hipSuccess)
+                return nullptr;
+            n = bytes + bytes / 4;
+        }
+        return p;
+    }
+};
+
 } // namespace
 
+void *jpegamd_pinned_scratch(size_t bytes)
+{
+    static thread_local PinnedScratch scratch;
+    return scratch.ensure(bytes);
+}
+
+// huffman_decode of the three planes of a file in one go (round 3): ONE upload of the payload range, ONE of
+// the three planes' tables, every kernel of every plane queued without a wait, ONE read-back of the three
+// (changed, total) words -- the only synchronisation -- and then the emit kernels.  Round 2 ran plane
+// after plane with five synchronous table copies, two read-backs and a device synchronisation each
+// (1.7 ms for 0.8 ms of kernels at 8192^2).  rc[k]: 0 decoded, 2 the host decoder must take plane k.
+int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_sym[3], const size_t cap[3], size_t n[3],
+                                 int rc[3])
+{
+    JpegamdDecodeTables tab[3];
+    size_t off[3], span = 0, tab_words[3], tab_total = 0;
+    bool live[3];
+    for (int k = 0; k < 3; ++k) {
+        n[k] = 0, rc[k] = 0;
+        off[k] = (size_t)(parts.payload[k] - parts.payload[0]); // contiguous in the file (jpegamd_bin_parse)
+        span = off[k] + parts.len[k];
+        live[k] = false;
+        tab_words[k] = 0;
+        if (parts.len[k] == 0)
+            continue;
+        if (parts.len[k] >= ((size_t)1 << 28)) { // bit positions are 32-bit here
+            rc[k] = 2;
+            continue;
+        }
+        rc[k] = jpegamd_decode_tables(parts.dict[k], parts.dsz[k], tab[k]);
+        if (rc[k] == 1)
+            return 1;
+        if (rc[k] == 0) {
+            live[k] = true;
+            tab_words[k] = tab[k].window.size() + 3 * tab[k].left.size();
+            tab_total += tab_words[k];
+        }
+    }
+    if (!live[0] && !live[1] && !live[2])
+        return 0;
+    // device memory: the payload range (+ two spare words), the tables, and per plane: sub_count (16-byte
+    // aligned: the scan reads four at a time), sub_start, workgroup ends a/b; in front of them the three
+    // status records {changed, pad, total(8)}
+    uint32_t n_sub[3] = {0, 0, 0}, n_wg[3] = {0, 0, 0};
+    size_t work_off[3], work_words = 16; // 3 x 4 words of status, padded to 64 bytes
+    for (int k = 0; k < 3; ++k) {
+        if (!live[k])
+            continue;
+        const uint32_t n_bits = (uint32_t)(parts.len[k] * 8);
+        n_sub[k] = (n_bits + kSubBits - 1) / kSubBits;
+        n_wg[k] = (n_sub[k] + kThreads - 1) / kThreads;
+        work_off[k] = work_words;
+        const size_t n_sub_pad = ((size_t)n_sub[k] + 3) & ~(size_t)3;
+        work_words += 2 * n_sub_pad + 2 * (((size_t)n_wg[k] + 3) & ~(size_t)3);
+    }
+    DevMem d_pay, d_tab, d_work;
+    if (d_pay.alloc(((span + 3) / 4 + 2) * 4) || d_tab.alloc(tab_total * 4) || d_work.alloc(work_words * 4))
+        return jpegamd_fail("entropy decode: out of device memory");
+    uint32_t *pinned = static_cast<uint32_t *>(jpegamd_pinned_scratch(tab_total * 4 + 64));
+    if (!pinned)
+        return jpegamd_fail("entropy decode: no pinned host memory");
+    if (span >= (1u << 20)) {
+        JPEGAMD_HIPCHK(hipDeviceSynchronize()); // (the copier runs on its own streams)
+        if (jpegamd_staged_copy_linear(d_pay.p, const_cast<uint8_t *>(parts.payload[0]), span, true))
+            return 1;
+    } else {
+        JPEGAMD_HIPCHK(hipMemcpy(d_pay.p, parts.payload[0], span, hipMemcpyHostToDevice));
+    }
+    uint32_t *status_back = pinned; // 16 words
+    uint32_t *tab_host = pinned + 16;
+    {
+        uint32_t *w = tab_host;
+        for (int k = 0; k < 3; ++k) {
+            if (!live[k])
+                continue;
+            const size_t nodes = tab[k].left.size();
+            std::memcpy(w, tab[k].window.data(), tab[k].window.size() * 4), w += tab[k].window.size();
+            std::memcpy(w, tab[k].left.data(), nodes * 4), w += nodes;
+            std::memcpy(w, tab[k].right.data(), nodes * 4), w += nodes;
+            std::memcpy(w, tab[k].value.data(), nodes * 4), w += nodes;
+        }
+    }
+    JPEGAMD_HIPCHK(hipMemcpyAsync(d_tab.p, tab_host, tab_total * 4, hipMemcpyHostToDevice, nullptr));
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_work.p, 0, 64, nullptr));
+    HdJob job{};
+    uint32_t wg_total = 0;
+    size_t tab_at = 0;
+    for (int k = 0; k < 3; ++k) {
+        HdPlane &pl = job.p[k];
+        pl.wg_begin = wg_total; // (a plane that is not decoded here has no workgroups: the next one begins at the same index)
+        if (!live[k])
+            continue;
+        const size_t nodes = tab[k].left.size();
+        pl.window = d_tab.as<uint32_t>() + tab_at;
+        const int32_t *d_left = reinterpret_cast<const int32_t *>(pl.window + tab[k].window.size());
+        tab_at += tab_words[k];
+        const uint32_t lead = (uint32_t)(off[k] & 3);
+        pl.s = Stream{d_pay.as<uint32_t>() + (off[k] >> 2), (uint32_t)((lead + parts.len[k] + 3) / 4),
+                      (uint32_t)(parts.len[k] * 8), 8 * lead, d_left, d_left + nodes, d_left + 2 * nodes};
+        const size_t n_sub_pad = ((size_t)n_sub[k] + 3) & ~(size_t)3;
+        pl.n_sub = n_sub[k];
+        pl.sub_count = d_work.as<uint32_t>() + work_off[k];
+        pl.sub_start = pl.sub_count + n_sub_pad;
+        pl.ends_a = pl.sub_start + n_sub_pad;
+        pl.ends_b = pl.ends_a + (((size_t)n_wg[k] + 3) & ~(size_t)3);
+        pl.changed = d_work.as<uint32_t>() + 4 * k;
+        pl.total = reinterpret_cast<unsigned long long *>(pl.changed + 2);
+        pl.out = cap[k] ? d_sym[k] : nullptr;
+        pl.cap = d_sym[k] ? cap[k] : 0;
+        wg_total += n_wg[k];
+    }
+    hipLaunchKernelGGL(hd_sync_kernel, dim3(wg_total), dim3(kThreads), 0, nullptr, job, 0);
+    // across workgroup boundaries: twice, the second time nothing may change any more (the first of the two
+    // raises `changed` too: the flags are cleared between them, in stream order)
+    hipLaunchKernelGGL(hd_sync_kernel, dim3(wg_total), dim3(kThreads), 0, nullptr, job, 1);
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_work.p, 0, 64, nullptr));
+    hipLaunchKernelGGL(hd_sync_kernel, dim3(wg_total), dim3(kThreads), 0, nullptr, job, 2);
+    hipLaunchKernelGGL(hd_scan_kernel, dim3(3), dim3(1024), 0, nullptr, job);
+    JPEGAMD_HIPCHK(hipGetLastError());
+    JPEGAMD_HIPCHK(hipMemcpyAsync(status_back, d_work.p, 48, hipMemcpyDeviceToHost, nullptr));
+    JPEGAMD_HIPCHK(hipStreamSynchronize(nullptr)); // the one wait of the stage
+    bool emitted = false;
+    HdJob emit = job; // planes that settled and have somewhere to go, renumbered
+    uint32_t emit_wgs = 0;
+    for (int k = 0; k < 3; ++k) {
+        emit.p[k].wg_begin = emit_wgs;
+        if (!live[k])
+            continue;
+        if (status_back[4 * k]) {
+            rc[k] = 2; // a chunk that does not fall into step within a workgroup's reach: the host decoder knows how
+            continue;
+        }
+        unsigned long long total;
+        std::memcpy(&total, status_back + 4 * k + 2, 8);
+        n[k] = (size_t)total;
+        if (emit.p[k].out && emit.p[k].cap)
+            emit_wgs += n_wg[k], emitted = true;
+    }
+    if (emitted)
+        hipLaunchKernelGGL(hd_emit_kernel, dim3(emit_wgs), dim3(kThreads), 0, nullptr, emit);
+    JPEGAMD_HIPCHK(hipGetLastError());
+    // Inside a context call the buffers are arena slots that outlive this function, and whatever reads the
+    // symbols next is queued behind the emit kernels on the same (null) stream: no wait.  Per-call buffers
+    // are freed on return: wait for the kernels that read them.
+    if (emitted && !jpegamd_thread_arena())
+        JPEGAMD_HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+// one plane (kept for callers that have a single payload)
 int jpegamd_device_decode_plane(const uint8_t *payload, size_t len, const uint8_t *dict, int dsz, int32_t *d_sym,
                                 size_t cap, size_t *n)
 {
-    *n = 0;
-    if (len == 0)
-        return 0;
-    if (len >= ((size_t)1 << 28)) // bit positions are 32-bit here
-        return 2;
-    JpegamdDecodeTables tab;
-    const int rc = jpegamd_decode_tables(dict, dsz, tab);
-    if (rc)
-        return rc;
-    const uint32_t n_bits = (uint32_t)(len * 8);
-    const uint32_t n_words = (uint32_t)((len + 3) / 4);
-    const uint32_t n_sub = (n_bits + kSubBits - 1) / kSubBits;
-    const uint32_t n_wg = (n_sub + kThreads - 1) / kThreads;
-    const size_t nodes = tab.left.size();
-    DevMem d_pay, d_tab, d_work;
-    // work: total (8 B), changed flag (+ pad), sub_count (16-byte aligned: the scan reads it four at a
-    // time), sub_start (n_sub each, rounded up to four), wg ends a/b (n_wg each)
-    const size_t n_sub_pad = ((size_t)n_sub + 3) & ~(size_t)3;
-    const size_t work_words = 4 + 2 * n_sub_pad + 2 * (size_t)n_wg;
-    if (d_pay.alloc(((size_t)n_words + 2) * 4) || d_tab.alloc((tab.window.size() + 3 * nodes) * 4) ||
-        d_work.alloc(work_words * 4))
-        return jpegamd_fail("entropy decode: out of device memory");
-    // payload: the last word and the two spare ones zeroed, then the bytes
-    JPEGAMD_HIPCHK(hipMemsetAsync(d_pay.as<uint32_t>() + (n_words - 1), 0, 12, nullptr));
-    if (len >= (1u << 20)) {
-        JPEGAMD_HIPCHK(hipDeviceSynchronize());
-        if (jpegamd_staged_copy_linear(d_pay.p, const_cast<uint8_t *>(payload), len, true))
-            return 1;
-    } else {
-        JPEGAMD_HIPCHK(hipMemcpy(d_pay.p, payload, len, hipMemcpyHostToDevice));
-    }
-    uint32_t *d_window = d_tab.as<uint32_t>();
-    int32_t *d_left = reinterpret_cast<int32_t *>(d_window + tab.window.size());
-    int32_t *d_right = d_left + nodes, *d_value = d_right + nodes;
-    JPEGAMD_HIPCHK(hipMemcpy(d_window, tab.window.data(), tab.window.size() * 4, hipMemcpyHostToDevice));
-    JPEGAMD_HIPCHK(hipMemcpy(d_left, tab.left.data(), nodes * 4, hipMemcpyHostToDevice));
-    JPEGAMD_HIPCHK(hipMemcpy(d_right, tab.right.data(), nodes * 4, hipMemcpyHostToDevice));
-    JPEGAMD_HIPCHK(hipMemcpy(d_value, tab.value.data(), nodes * 4, hipMemcpyHostToDevice));
-    unsigned long long *total = d_work.as<unsigned long long>();
-    uint32_t *changed = d_work.as<uint32_t>() + 2;
-    uint32_t *sub_count = changed + 2, *sub_start = sub_count + n_sub_pad;
-    uint32_t *ends_a = sub_start + n_sub_pad, *ends_b = ends_a + n_wg;
-    JPEGAMD_HIPCHK(hipMemsetAsync(d_work.p, 0, 16, nullptr));
-    const Stream s{d_pay.as<uint32_t>(), n_words, n_bits, d_left, d_right, d_value};
-    hipLaunchKernelGGL(hd_sync_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, s, d_window, n_sub, sub_start, sub_count,
-                       (const uint32_t *)nullptr, ends_a, changed);
-    // across workgroup boundaries: twice, the second time nothing may change any more
-    hipLaunchKernelGGL(hd_sync_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, s, d_window, n_sub, sub_start, sub_count,
-                       (const uint32_t *)ends_a, ends_b, changed);
-    JPEGAMD_HIPCHK(hipMemsetAsync(changed, 0, 4, nullptr));
-    hipLaunchKernelGGL(hd_sync_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, s, d_window, n_sub, sub_start, sub_count,
-                       (const uint32_t *)ends_b, ends_a, changed);
-    hipLaunchKernelGGL(hd_scan_kernel, dim3(1), dim3(1024), 0, nullptr, sub_count, n_sub, total);
-    JPEGAMD_HIPCHK(hipGetLastError());
-    struct {
-        uint32_t changed, pad;
-        unsigned long long total;
-    } back = {0, 0, 0};
-    JPEGAMD_HIPCHK(hipMemcpy(&back.changed, changed, 4, hipMemcpyDeviceToHost));
-    JPEGAMD_HIPCHK(hipMemcpy(&back.total, total, 8, hipMemcpyDeviceToHost));
-    if (back.changed)
-        return 2; // a chunk that does not fall into step within a workgroup's reach: the host decoder knows how
-    *n = (size_t)back.total;
-    if (cap && d_sym) {
-        hipLaunchKernelGGL(hd_emit_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, s, d_window, n_sub, sub_start,
-                           sub_count, d_sym, cap);
-        JPEGAMD_HIPCHK(hipGetLastError());
-        JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the tables and the payload go out of scope
-    }
-    return 0;
+    JpegamdBinParts parts{};
+    for (int k = 0; k < 3; ++k)
+        parts.payload[k] = payload + (k ? len : 0), parts.len[k] = 0, parts.dict[k] = dict, parts.dsz[k] = 0;
+    parts.len[0] = len, parts.dsz[0] = dsz;
+    int32_t *const syms[3] = {d_sym, nullptr, nullptr};
+    const size_t caps[3] = {cap, 0, 0};
+    size_t ns[3];
+    int rcs[3];
+    if (jpegamd_device_decode_planes(parts, syms, caps, ns, rcs))
+        return 1;
+    *n = ns[0];
+    return rcs[0];
 }

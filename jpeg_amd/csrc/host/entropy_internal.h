@@ -71,4 +71,12 @@ JPEGAMD_HIDDEN int jpegamd_host_decode_plane(const uint8_t *payload, size_t len,
 // the host decoder must take over, 1 on error.
 JPEGAMD_HIDDEN int jpegamd_device_decode_plane(const uint8_t *payload, size_t len, const uint8_t *dict, int dsz,
                                                int32_t *d_sym, size_t cap, size_t *n);
+// The three planes of a parsed file in one go (one upload of the payload range, one of the tables, one wait).
+// rc[k]: 0 = decoded (n[k] symbols found, min(n[k], cap[k]) written to d_sym[k] if it is not null), 2 = the host
+// decoder must take plane k.  Returns 1 on error.  The emit kernels are left running on the null stream when the
+// call runs inside a context (the arena's buffers outlive it); otherwise the device is synchronised.
+JPEGAMD_HIDDEN int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_sym[3], const size_t cap[3],
+                                                size_t n[3], int rc[3]);
+// pinned host scratch of the calling thread, at least `bytes` (grows, lives as long as the thread); null on failure
+JPEGAMD_HIDDEN void *jpegamd_pinned_scratch(size_t bytes);
 #endif

@@ -327,22 +327,23 @@ static int decompress_image_impl(const uint8_t *bin, size_t len, const int32_t q
     // huffman_decode (encode_decode.cpp:468-482) on the device; a plane the device tables do not
     // cover (or JPEGAMD_ENTROPY=host) is decoded on the host and its symbols uploaded
     size_t n[3] = {0, 0, 0};
+    int prc[3] = {2, 2, 2};
+    int32_t *const d_sym_p[3] = {d_sym[0].as<int32_t>(), d_sym[1].as<int32_t>(), d_sym[2].as<int32_t>()};
+    if (!entropy_on_host() && jpegamd_device_decode_planes(parts, d_sym_p, cap, n, prc))
+        return 1;
     for (int k = 0; k < 3; ++k) {
-        int rc = entropy_on_host() ? 2
-                                   : jpegamd_device_decode_plane(parts.payload[k], parts.len[k], parts.dict[k],
-                                                                 parts.dsz[k], d_sym[k].as<int32_t>(), cap[k], &n[k]);
-        if (rc == 2) {
+        if (prc[k] == 2) { // the host decoder's cases (see jpegamd_decode_tables), or a stream that did not settle
             HostSymbols sym;
             if (!sym.resize(cap[k]))
                 return jpegamd_fail("decompress_image: out of host memory");
-            rc = jpegamd_host_decode_plane(parts.payload[k], parts.len[k], parts.dict[k], parts.dsz[k], sym.data(), cap[k],
-                                           &n[k], 16);
+            if (jpegamd_host_decode_plane(parts.payload[k], parts.len[k], parts.dict[k], parts.dsz[k], sym.data(), cap[k], &n[k],
+                                          16))
+                return 1;
             const size_t have = n[k] < cap[k] ? n[k] : cap[k];
-            if (!rc && have && jpegamd_staged_copy_linear(d_sym[k].p, sym.data(), have * 4, true))
+            JPEGAMD_HIPCHK(hipDeviceSynchronize()); // (the copier runs on its own streams)
+            if (have && jpegamd_staged_copy_linear(d_sym[k].p, sym.data(), have * 4, true))
                 return 1;
         }
-        if (rc)
-            return 1;
         if (n[k] > cap[k])
             return jpegamd_fail("decompress_image: plane %d decodes to %zu symbols, more than its %zu blocks can hold", k,
                                 n[k], nb[k]);
@@ -384,25 +385,29 @@ static int bin_decode_dev_impl(const uint8_t *bin, size_t len, int32_t dims[6], 
         return 1;
     std::memcpy(dims, parts.dims, sizeof parts.dims);
     bool small = false;
+    int prc[3] = {2, 2, 2};
+    size_t use_cap[3];
+    for (int k = 0; k < 3; ++k)
+        use_cap[k] = d_sym[k] ? cap[k] : 0;
+    if (!entropy_on_host() && jpegamd_device_decode_planes(parts, d_sym, use_cap, n, prc))
+        return 1;
     for (int k = 0; k < 3; ++k) {
-        int rc = entropy_on_host() ? 2
-                                   : jpegamd_device_decode_plane(parts.payload[k], parts.len[k], parts.dict[k],
-                                                                 parts.dsz[k], d_sym[k], d_sym[k] ? cap[k] : 0, &n[k]);
-        if (rc == 2) { // the host decoder's cases: see jpegamd_decode_tables
+        if (prc[k] == 2) { // the host decoder's cases: see jpegamd_decode_tables
             HostSymbols sym;
-            const size_t c = d_sym[k] ? cap[k] : 0;
+            const size_t c = use_cap[k];
             if (!sym.resize(c))
                 return jpegamd_fail("bin_decode_dev: out of host memory");
-            rc = jpegamd_host_decode_plane(parts.payload[k], parts.len[k], parts.dict[k], parts.dsz[k], c ? sym.data() : nullptr,
-                                           c, &n[k], 16);
+            if (jpegamd_host_decode_plane(parts.payload[k], parts.len[k], parts.dict[k], parts.dsz[k], c ? sym.data() : nullptr, c,
+                                          &n[k], 16))
+                return 1;
             const size_t have = n[k] < c ? n[k] : c;
-            if (!rc && have && jpegamd_staged_copy_linear(d_sym[k], sym.data(), have * 4, true))
+            JPEGAMD_HIPCHK(hipDeviceSynchronize());
+            if (have && jpegamd_staged_copy_linear(d_sym[k], sym.data(), have * 4, true))
                 return 1;
         }
-        if (rc)
-            return 1;
         small = small || n[k] > cap[k] || !d_sym[k];
     }
+    JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the symbols are the caller's from here on
     if (small)
         return jpegamd_fail("bin_decode: symbol buffer too small (the counts needed are in n[0..2])");
     return 0;
