@@ -340,8 +340,9 @@ def bin_encode_dev(sym_y, sym_cb, sym_cr, y_rows, y_cols):
     ptrs = [_dev(x, torch.int32, "bin_encode_dev") if x.numel() else 0 for x in s]
     need = ctypes.c_size_t(0)
     args = [v for p, x in zip(ptrs, s) for v in (p, x.numel())] + [int(y_rows), int(y_cols), int(y_rows) // 2, int(y_cols) // 2]
-    lib.jpegamd_bin_encode_dev(*args, None, 0, ctypes.byref(need))  # sizing call
-    out = np.empty(need.value, np.uint8)
+    # ONE call (a sizing call would run the whole stage twice): a symbol's code is at most 32 bits here, a
+    # dictionary at most 64 Ki entries of 8 bytes per plane; the pages of the unused rest are never touched
+    out = np.empty(48 + 4 * sum(x.numel() for x in s) + 3 * 8 * 65536, np.uint8)
     _lib.check(lib.jpegamd_bin_encode_dev(*args, out.ctypes.data, out.size, ctypes.byref(need)))
     return out[:need.value].tobytes()
 

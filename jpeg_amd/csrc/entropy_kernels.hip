@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "host/dev_alloc.h"
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void sym_pack_kernel(const int32_t *__res
                                                             const uint32_t *__restrict__ cbits,
                                                             const uint8_t *__restrict__ clen,
                                                             const unsigned long long *__restrict__ wg_off,
-                                                            uint32_t *__restrict__ payload)
+                                                            uint32_t *__restrict__ payload, unsigned long long bit_base)
 {
     __shared__ uint32_t wave_tot[kThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void sym_pack_kernel(const int32_t *__res
     uint32_t before = 0;
     for (int w = 0; w < kThreads / 64; ++w)
         before += w < wave ? wave_tot[w] : 0;
-    unsigned long long pos = wg_off[blockIdx.x] + before + inc - mine; // first bit of this thread
+    unsigned long long pos = bit_base + wg_off[blockIdx.x] + before + inc - mine; // first bit of this thread (bit_base: where the plane begins in `payload`)
     // BitWriter (host/bin_container.cpp) with the partial first word as leading zero bits
     unsigned long long acc = 0;
     int have = (int)(pos & 31);
@@ -256,7 +257,7 @@ int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode
     hipLaunchKernelGGL(wg_offsets_kernel, dim3(1), dim3(1024), 0, nullptr, sums.as<uint32_t>(), n_wg,
                        offs.as<unsigned long long>());
     hipLaunchKernelGGL(sym_pack_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, d_sym, n32, d_cbits, d_clen,
-                       offs.as<unsigned long long>(), out.as<uint32_t>());
+                       offs.as<unsigned long long>(), out.as<uint32_t>(), 0ull);
     JPEGAMD_HIPCHK(hipGetLastError());
     if (bytes >= (1u << 20)) { // through the pinned staging buffers: pageable hipMemcpy moves a fifth of that
         JPEGAMD_HIPCHK(hipDeviceSynchronize());
@@ -265,5 +266,137 @@ int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode
     } else {
         JPEGAMD_HIPCHK(hipMemcpy(pl.payload.data(), out.p, bytes, hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+
+// The entropy stage of the three planes of an image in one go (round 3).  Round 2 ran plane after plane:
+// three memsets, the histogram, three synchronous read-backs, the host's code construction, two synchronous
+// table uploads, three kernels and a synchronous payload copy EACH (1.2 ms for 0.26 ms of kernels at 8192^2).
+// Here: the three histograms are queued together and their flags and windows come back in ONE wait (through
+// pinned memory); the host builds the three codes; tables go up and the nine kernels are queued without a
+// wait; the packed payloads land in ONE device buffer laid out like the file's payload section (planes back
+// to back at byte granularity: encode_decode.cpp:1178-1186), which the caller copies straight into the
+// file image (jpegamd_bin_assemble_from_device) -- no per-plane host vectors, no second copy.
+// Returns 0 (code[k].dict filled, bytes[k] = payload bytes of plane k, d_out = the payload section, kernels
+// still running on the null stream), 2 when some plane needs the host path (nothing is left behind), 1 on error.
+int jpegamd_device_encode_image(const int32_t *const d_sym[3], const size_t n[3], JpegamdPlaneCode code[3], size_t bytes[3],
+                                JpegamdDevMem &d_out)
+{
+    for (int k = 0; k < 3; ++k) {
+        code[k].dict.clear(), code[k].payload.clear();
+        bytes[k] = 0;
+        if (n[k] >= 0xFFFFFFFFull)
+            return 2;
+    }
+    // counters of the three planes: count[3][64 Ki], first[3][64 Ki], bad[4]
+    DevMem ctr;
+    if (ctr.alloc((6 * (size_t)kKeys + 4) * sizeof(uint32_t)))
+        return jpegamd_fail("entropy stage: out of device memory");
+    uint32_t *d_count = ctr.as<uint32_t>(), *d_first = d_count + 3 * kKeys, *d_bad = d_first + 3 * kKeys;
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_count, 0, 3 * (size_t)kKeys * sizeof(uint32_t), nullptr));
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_first, 0xFF, 3 * (size_t)kKeys * sizeof(uint32_t), nullptr));
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_bad, 0, 4 * sizeof(uint32_t), nullptr));
+    for (int k = 0; k < 3; ++k) {
+        if (!n[k])
+            continue;
+        const uint32_t n32 = (uint32_t)n[k];
+        const uint32_t hist_grid = std::min<uint32_t>((n32 + kThreads - 1) / kThreads, 2048);
+        hipLaunchKernelGGL(sym_hist_kernel, dim3(hist_grid), dim3(kThreads), 0, nullptr, d_sym[k], n32, d_count + k * kKeys,
+                           d_first + k * kKeys, d_bad + k);
+    }
+    JPEGAMD_HIPCHK(hipGetLastError());
+    // back through pinned memory, one wait: the flags and, optimistically, only the windows' 2 x 8 KB per plane
+    // (a key outside the window -- which coefficients and runs of an image never are -- costs that plane two more copies)
+    const int w0 = 32768 - kWin / 2;
+    const size_t pin_words = 4 + 6 * (size_t)kWin;
+    uint32_t *pin = static_cast<uint32_t *>(jpegamd_pinned_scratch((pin_words + 3 * ((size_t)kWin * 5 / 4 + 4)) * 4));
+    if (!pin)
+        return jpegamd_fail("entropy stage: no pinned host memory");
+    JPEGAMD_HIPCHK(hipMemcpyAsync(pin, d_bad, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, nullptr));
+    for (int k = 0; k < 3; ++k) {
+        JPEGAMD_HIPCHK(hipMemcpyAsync(pin + 4 + (2 * k) * kWin, d_count + k * kKeys + w0, kWin * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, nullptr));
+        JPEGAMD_HIPCHK(hipMemcpyAsync(pin + 4 + (2 * k + 1) * kWin, d_first + k * kKeys + w0, kWin * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, nullptr));
+    }
+    JPEGAMD_HIPCHK(hipStreamSynchronize(nullptr)); // wait 1 of 2
+    std::vector<uint32_t> h(2 * (size_t)kKeys);
+    std::vector<uint32_t> cbits[3];
+    std::vector<uint8_t> clen[3];
+    int win0[3], winn[3];
+    size_t total_bytes = 0;
+    for (int k = 0; k < 3; ++k) {
+        win0[k] = w0, winn[k] = kWin;
+        if (!n[k])
+            continue;
+        if (pin[k] & 1u)
+            return 2; // a symbol outside int16: the host path has the general tables
+        std::fill(h.begin(), h.end(), 0u);
+        if (pin[k] & 2u) { // keys outside the window: the whole tables
+            win0[k] = 0, winn[k] = kKeys;
+            JPEGAMD_HIPCHK(hipMemcpy(h.data(), d_count + k * kKeys, kKeys * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            JPEGAMD_HIPCHK(hipMemcpy(h.data() + kKeys, d_first + k * kKeys, kKeys * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        } else {
+            std::memcpy(h.data() + w0, pin + 4 + (2 * k) * kWin, kWin * sizeof(uint32_t));
+            std::memcpy(h.data() + kKeys + w0, pin + 4 + (2 * k + 1) * kWin, kWin * sizeof(uint32_t));
+        }
+        // distinct symbols in first-occurrence order: the insertion sequence of the reference's map
+        std::vector<int> order;
+        for (int key = win0[k]; key < win0[k] + winn[k]; ++key)
+            if (h[key])
+                order.push_back(key - 32768);
+        const uint32_t *first = h.data() + kKeys;
+        std::sort(order.begin(), order.end(), [first](int a, int b) { return first[a + 32768] < first[b + 32768]; });
+        unsigned long long total_bits = 0;
+        const int rc = jpegamd_codes_from_order(order, h.data(), code[k], cbits[k], clen[k], total_bits);
+        if (rc)
+            return rc;
+        bytes[k] = (size_t)((total_bits + 7) / 8);
+        if (bytes[k] > 0x7FFFFFFFu)
+            return jpegamd_fail("bin_encode: payload exceeds the container's int32 length field");
+        total_bytes += bytes[k];
+    }
+    const size_t words = (total_bytes + 3) / 4 + 2;
+    if (d_out.alloc(words * 4))
+        return jpegamd_fail("entropy stage: out of device memory");
+    if (total_bytes == 0)
+        return 0; // (single distinct symbols have the empty code, encode_decode.cpp:444-456)
+    JPEGAMD_HIPCHK(hipMemsetAsync(d_out.p, 0, words * 4, nullptr));
+    // tables up from pinned memory (only the entries of keys in use are ever read), kernels queued behind them
+    DevMem tab[3], sums[3], offs[3];
+    uint8_t *pin_tab = reinterpret_cast<uint8_t *>(pin + pin_words);
+    size_t bit_base = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (!bytes[k])
+            continue; // no symbols, or one distinct symbol: no bits
+        const uint32_t n32 = (uint32_t)n[k];
+        const uint32_t n_wg = (n32 + kPerWg - 1) / kPerWg;
+        if (tab[k].alloc(kKeys * 5) || sums[k].alloc(n_wg * sizeof(uint32_t)) || offs[k].alloc(n_wg * sizeof(unsigned long long)))
+            return jpegamd_fail("entropy stage: out of device memory");
+        uint32_t *d_cbits = tab[k].as<uint32_t>();
+        uint8_t *d_clen = reinterpret_cast<uint8_t *>(d_cbits + kKeys);
+        if (winn[k] == kWin) {
+            uint8_t *pt = pin_tab + (size_t)k * (kWin * 5 + 16);
+            std::memcpy(pt, cbits[k].data() + w0, kWin * 4);
+            std::memcpy(pt + kWin * 4, clen[k].data() + w0, kWin);
+            JPEGAMD_HIPCHK(hipMemcpyAsync(d_cbits + w0, pt, kWin * 4, hipMemcpyHostToDevice, nullptr));
+            JPEGAMD_HIPCHK(hipMemcpyAsync(d_clen + w0, pt + kWin * 4, kWin, hipMemcpyHostToDevice, nullptr));
+        } else {
+            JPEGAMD_HIPCHK(hipMemcpy(d_cbits, cbits[k].data(), (size_t)kKeys * 4, hipMemcpyHostToDevice));
+            JPEGAMD_HIPCHK(hipMemcpy(d_clen, clen[k].data(), (size_t)kKeys, hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(sym_bits_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, d_sym[k], n32, d_clen, sums[k].as<uint32_t>());
+        hipLaunchKernelGGL(wg_offsets_kernel, dim3(1), dim3(1024), 0, nullptr, sums[k].as<uint32_t>(), n_wg,
+                           offs[k].as<unsigned long long>());
+        hipLaunchKernelGGL(sym_pack_kernel, dim3(n_wg), dim3(kThreads), 0, nullptr, d_sym[k], n32, d_cbits, d_clen,
+                           offs[k].as<unsigned long long>(), d_out.as<uint32_t>(), (unsigned long long)bit_base * 8);
+        bit_base += bytes[k];
+    }
+    JPEGAMD_HIPCHK(hipGetLastError());
+    // tab / sums / offs: arena slots inside a context call (they outlive this function); per-call buffers
+    // are freed on return, so wait for the kernels that use them
+    if (!jpegamd_thread_arena())
+        JPEGAMD_HIPCHK(hipDeviceSynchronize());
     return 0;
 }

@@ -34,6 +34,17 @@ JPEGAMD_HIDDEN int jpegamd_bin_assemble(const JpegamdPlaneCode (&pl)[3], int y_r
 // outside int16, a code longer than 32 bits, 2^32 symbols or more), 1 on error.
 JPEGAMD_HIDDEN int jpegamd_device_encode_plane(const int32_t *d_sym, size_t n, JpegamdPlaneCode &pl);
 
+// The same for the three planes of an image in one go (two waits in all): code[k].dict filled (payload left
+// empty), bytes[k] = payload bytes of plane k, d_out = the file's payload section on the device (planes back to
+// back), its kernels still running on the null stream.  0 / 2 (some plane needs the host path) / 1.
+struct JpegamdDevMem;
+JPEGAMD_HIDDEN int jpegamd_device_encode_image(const int32_t *const d_sym[3], const size_t n[3], JpegamdPlaneCode code[3],
+                                               size_t bytes[3], JpegamdDevMem &d_out);
+// saveEncodedData's layout with the payload section copied straight from the device into the file image
+JPEGAMD_HIDDEN int jpegamd_bin_assemble_from_device(const JpegamdPlaneCode (&pl)[3], const size_t bytes[3], const void *d_payloads,
+                                                    int y_rows, int y_cols, int c_rows, int c_cols, uint8_t *out, size_t cap,
+                                                    size_t *out_len);
+
 // Decoding tables of one plane from its dictionary as stored in the file (dsz (key, frequency)
 // int32 pairs): the tree built exactly as decodeChannel does (encode_decode.cpp:664: the pairs go
 // through a std::unordered_map first), flattened for the device decoder.

@@ -80,8 +80,63 @@ bool entropy_on_host()
 }
 
 // fused encode + run-length stage (jpegamd_encode_image_rle_dev) and entropy stage
+// The coded planes of an image: either whole on the host (code[k].payload), or -- the usual case -- the
+// dictionaries on the host and the payload section still on the device, to be copied straight into the file
+struct CodedImage {
+    JpegamdPlaneCode code[3];
+    bool payload_on_device = false;
+    size_t bytes[3] = {0, 0, 0};
+    DevMem d_payloads;
+    int assemble(int y_rows, int y_cols, int c_rows, int c_cols, uint8_t *out, size_t cap, size_t *out_len) const
+    {
+        if (payload_on_device)
+            return jpegamd_bin_assemble_from_device(code, bytes, d_payloads.p, y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
+        return jpegamd_bin_assemble(code, y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
+    }
+    size_t file_bytes() const
+    {
+        size_t need = 9 * 4 + 3 * 4;
+        for (int k = 0; k < 3; ++k)
+            need += (payload_on_device ? bytes[k] : code[k].payload.size()) + 8 * code[k].dict.size();
+        return need;
+    }
+};
+
+// entropy stage of three symbol streams on the device: all three planes in one go, or plane by plane with
+// the host coder for what the device tables do not cover
+int code_streams(const int32_t *const d_sym[3], const size_t n[3], CodedImage &ci, const char *what)
+{
+    if (!entropy_on_host()) {
+        const int rc = jpegamd_device_encode_image(d_sym, n, ci.code, ci.bytes, ci.d_payloads);
+        if (rc == 0) {
+            ci.payload_on_device = true;
+            return 0;
+        }
+        if (rc != 2)
+            return rc;
+    }
+    ci.payload_on_device = false;
+    for (int k = 0; k < 3; ++k) {
+        if (!entropy_on_host()) {
+            const int rc = jpegamd_device_encode_plane(d_sym[k], n[k], ci.code[k]);
+            if (rc == 0)
+                continue;
+            if (rc != 2)
+                return rc;
+        }
+        HostSymbols sym; // the host path: the pairs are the memory of the reference's std::vector<int>
+        if (!sym.resize(n[k]))
+            return jpegamd_fail("%s: out of host memory", what);
+        if (n[k] && jpegamd_staged_copy_linear(const_cast<int32_t *>(d_sym[k]), sym.data(), n[k] * 4, false))
+            return 1;
+        if (jpegamd_host_encode_plane(sym.data(), sym.size(), ci.code[k]))
+            return 1;
+    }
+    return 0;
+}
+
 int image_code(const uint8_t *d_bgr, int rows, int cols, const int32_t q_luma[64], const int32_t q_chroma[64],
-               int16_t *const d_coef[3], const size_t nb[3], JpegamdPlaneCode code[3], StageTrace &trace)
+               int16_t *const d_coef[3], const size_t nb[3], CodedImage &ci, StageTrace &trace)
 {
     DevMem work, offs[3], pairs[3];
     const size_t wbytes = jpegamd_rle_workspace_bytes(nb[0] + nb[1] + nb[2]);
@@ -115,26 +170,48 @@ int image_code(const uint8_t *d_bgr, int rows, int cols, const int32_t q_luma[64
             return jpegamd_fail("compress_image: run-length pass did not converge");
     }
     trace.mark("transform+run-length");
-    for (int k = 0; k < 3; ++k) {
-        if (!entropy_on_host()) {
-            const int rc = jpegamd_device_encode_plane(pairs[k].as<int32_t>(), (size_t)total[k] * 2, code[k]);
-            if (rc == 0)
-                continue;
-            if (rc != 2)
-                return rc;
-        }
-        HostSymbols sym; // the host path: the pairs are the memory of the reference's std::vector<int>
-        if (!sym.resize((size_t)total[k] * 2))
-            return jpegamd_fail("compress_image: out of host memory");
-        if (total[k] && jpegamd_staged_copy_linear(pairs[k].p, sym.data(), (size_t)total[k] * 8, false))
-            return 1;
-        if (jpegamd_host_encode_plane(sym.data(), sym.size(), code[k]))
-            return 1;
-    }
-    return 0;
+    const int32_t *const d_sym[3] = {pairs[0].as<int32_t>(), pairs[1].as<int32_t>(), pairs[2].as<int32_t>()};
+    const size_t n_sym[3] = {(size_t)total[0] * 2, (size_t)total[1] * 2, (size_t)total[2] * 2};
+    return code_streams(d_sym, n_sym, ci, "compress_image");
 }
 
 } // namespace
+
+int jpegamd_bin_assemble_from_device(const JpegamdPlaneCode (&pl)[3], const size_t bytes[3], const void *d_payloads, int y_rows,
+                                     int y_cols, int c_rows, int c_cols, uint8_t *out, size_t cap, size_t *out_len)
+{
+    size_t need = 9 * 4 + 3 * 4, payload = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (bytes[k] > 0x7FFFFFFFu)
+            return jpegamd_fail("bin_encode: payload exceeds the container's int32 length field");
+        payload += bytes[k];
+        need += bytes[k] + 8 * pl[k].dict.size();
+    }
+    *out_len = need;
+    if (!out || cap < need)
+        return jpegamd_fail("bin_encode: output buffer too small (the size needed is in *out_len)");
+    auto put = [](uint8_t *&w, int v) { std::memcpy(w, &v, 4), w += 4; }; // (little endian like the reference's fwrite of ints)
+    uint8_t *w = out;
+    put(w, y_rows), put(w, y_cols), put(w, c_rows), put(w, c_cols), put(w, c_rows), put(w, c_cols); // saveEncodedData, :1161-1217
+    for (int k = 0; k < 3; ++k)
+        put(w, (int)bytes[k]);
+    if (payload) {
+        JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the pack kernels ran on the null stream, the copier uses its own
+        if (payload >= (1u << 20)) {
+            if (jpegamd_staged_copy_linear(const_cast<void *>(d_payloads), w, payload, false))
+                return 1;
+        } else {
+            JPEGAMD_HIPCHK(hipMemcpy(w, d_payloads, payload, hipMemcpyDeviceToHost));
+        }
+        w += payload;
+    }
+    for (int k = 0; k < 3; ++k)
+        put(w, (int)pl[k].dict.size());
+    for (int k = 0; k < 3; ++k)
+        for (const auto &kv : pl[k].dict)
+            put(w, kv.first), put(w, kv.second);
+    return 0;
+}
 
 JpegamdArena *&jpegamd_thread_arena()
 {
@@ -227,24 +304,13 @@ static int bin_encode_dev_impl(const int32_t *d_sym_y, size_t n_y, const int32_t
 {
     if (!out_len || (!d_sym_y && n_y) || (!d_sym_cb && n_cb) || (!d_sym_cr && n_cr))
         return jpegamd_fail("bin_encode_dev: null pointer");
-    const int32_t *d_sym[3] = {d_sym_y, d_sym_cb, d_sym_cr};
+    const int32_t *const d_sym[3] = {d_sym_y, d_sym_cb, d_sym_cr};
     const size_t n[3] = {n_y, n_cb, n_cr};
-    JpegamdPlaneCode code[3];
     JPEGAMD_HIPCHK(hipDeviceSynchronize()); // the symbols may come from kernels on other streams
-    for (int k = 0; k < 3; ++k) {
-        int rc = entropy_on_host() ? 2 : jpegamd_device_encode_plane(d_sym[k], n[k], code[k]);
-        if (rc == 2) { // general tables (symbols beyond int16, codes beyond 32 bits): the host path
-            HostSymbols sym;
-            if (!sym.resize(n[k]))
-                return jpegamd_fail("bin_encode_dev: out of host memory");
-            if (n[k] && jpegamd_staged_copy_linear(const_cast<int32_t *>(d_sym[k]), sym.data(), n[k] * 4, false))
-                return 1;
-            rc = jpegamd_host_encode_plane(sym.data(), n[k], code[k]);
-        }
-        if (rc)
-            return 1;
-    }
-    return jpegamd_bin_assemble(code, y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
+    CodedImage ci;
+    if (code_streams(d_sym, n, ci, "bin_encode_dev"))
+        return 1;
+    return ci.assemble(y_rows, y_cols, c_rows, c_cols, out, cap, out_len);
 }
 
 static int compress_image_impl(const uint8_t *bgr, int rows, int cols, size_t stride, const int32_t q_luma[64],
@@ -264,18 +330,17 @@ static int compress_image_impl(const uint8_t *bgr, int rows, int cols, size_t st
     if (jpegamd_staged_copy(d_bgr.p, const_cast<uint8_t *>(bgr), stride, (size_t)cols * 3, rows, true))
         return 1;
     trace.mark("upload");
-    JpegamdPlaneCode code[3];
+    CodedImage ci;
     int16_t *const d_coef[3] = {d_y.as<int16_t>(), d_cb.as<int16_t>(), d_cr.as<int16_t>()};
     const size_t nbs[3] = {nby, nbc, nbc};
-    if (image_code(d_bgr.as<uint8_t>(), rows, cols, q_luma, q_chroma, d_coef, nbs, code, trace))
+    if (image_code(d_bgr.as<uint8_t>(), rows, cols, q_luma, q_chroma, d_coef, nbs, ci, trace))
         return 1;
     trace.mark("entropy");
-    size_t need = 0;
-    (void)jpegamd_bin_assemble(code, rows, cols, rows / 2, cols / 2, nullptr, 0, &need); // sizing call
+    size_t need = ci.file_bytes();
     uint8_t *buf = static_cast<uint8_t *>(std::malloc(need ? need : 1));
     if (!buf)
         return jpegamd_fail("compress_image: out of host memory");
-    if (jpegamd_bin_assemble(code, rows, cols, rows / 2, cols / 2, buf, need, &need)) {
+    if (ci.assemble(rows, cols, rows / 2, cols / 2, buf, need, &need)) {
         std::free(buf);
         return 1;
     }
