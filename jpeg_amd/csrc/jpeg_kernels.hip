@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/jpeg_amd.h"
@@ -177,6 +178,60 @@ __device__ __forceinline__ void rows_fdct_matrix_pipe(const uint8_t *src, int pi
     }
 }
 
+// ------------------------------------------------ typed loads for the colour stage
+// The texture path converts for free what the VALU pays 4.2 cycles per byte for: a typed buffer load with
+// the format 8_8_8_8 / USCALED returns four bytes as four floats 0.0 .. 255.0 (tools/typed_load_probe.hip),
+// so the three v_cvt_f32_ubyte per pixel of the colour stage (384 of a tile's 6300 instructions, and of the
+// slow class: profiles/r03_a section 5) disappear.  Floats cost four times the registers of the bytes, so
+// only ONE task is loaded ahead where the byte path has four to eight (2 rows x 12 floats per lane and task, two
+// buffers of 24 registers; with three waves per SIMD a wave reaches its next task about 2 us later).
+// clang has no builtin for format loads: they are inline assembly, the compiler does not know them as
+// memory operations and the wait is explicit (`s_waitcnt vmcnt(N)` before a task's floats are read, N = the loads
+// of the tasks issued after this one: all older memory operations have completed; coefficient stores issued
+// since only make the wait stricter).  Between a
+// load and its wait the registers are live asm operands, so the compiler keeps its hands off them; the
+// build checks that it has placed no copy of them in between (tools/check_typed_loads.py).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+struct TaskFloats {
+    f32x4 a[3], b[3]; // rows a and b of a task: 12 bytes each as floats (B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3)
+};
+// buffers of 24 registers: 2 = one task ahead (the registers the byte path's ring takes); 4 = three ahead, which
+// spills 49-62 registers next to the transform (measured: see DESIGN.md)
+#ifndef JPEGAMD_TYPED_BUFFERS
+#define JPEGAMD_TYPED_BUFFERS 2
+#endif
+constexpr int kTypedBufs = JPEGAMD_TYPED_BUFFERS;
+__device__ __forceinline__ u32x4_t make_bgr_resource(const uint8_t *base, uint32_t bytes)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    // word 3: dst_sel x, y, z, w = 4, 5, 6, 7; NUM_FORMAT USCALED (2); DATA_FORMAT 8_8_8_8 (10); type 0 = buffer
+    return u32x4_t{(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 4u | (5u << 3) | (6u << 6) | (7u << 9) | (2u << 12) | (10u << 15)};
+}
+__device__ __forceinline__ void typed_load_row(f32x4 (&f)[3], uint32_t voff, u32x4_t rsrc, uint32_t soff)
+{
+    asm volatile("tbuffer_load_format_xyzw %0, %3, %4, %5 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen\n\t"
+                 "tbuffer_load_format_xyzw %1, %3, %4, %5 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen offset:4\n\t"
+                 "tbuffer_load_format_xyzw %2, %3, %4, %5 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen offset:8"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2])
+                 : "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+// the task's floats may be read behind this
+__device__ __forceinline__ void wait_task_floats(TaskFloats &t)
+{
+    asm volatile("s_waitcnt vmcnt(%6)"
+                 : "+v"(t.a[0]), "+v"(t.a[1]), "+v"(t.a[2]), "+v"(t.b[0]), "+v"(t.b[1]), "+v"(t.b[2])
+                 : "n"(6 * (kTypedBufs - 2)) // the tasks issued after this one: six loads each
+                 : "memory");
+}
+// channel c of pixel j of a row held as floats
+template <int J, int C>
+__device__ __forceinline__ float row_float(const f32x4 (&f)[3])
+{
+    constexpr int idx = 3 * J + C;
+    return f[idx >> 2][idx & 3];
+}
+
 // ------------------------------------------------------------- fused encoder
 // grid: one wave per 512x16 tile, 4 waves per workgroup.
 // kCounts: also write, per block, the number of (value, run) pairs run_length_encode
@@ -188,7 +243,8 @@ struct CountPlanes {
 // kDump: stop after the colour stage and write the Y, Cb, Cr planes (RGB2YCbCr +
 // chromaSubsampling on their own: jpegamd_colour_planes_dev); `counts` then names the planes.
 // kPipe: 0 = both DCT passes on the VALU; 1 = the row pass on the 16-bit matrix pipe (above)
-template <bool kCounts, bool kDump, int kPipe = 0>
+// kTyped: the colour stage reads its pixels as floats through typed buffer loads (above)
+template <bool kCounts, bool kDump, int kPipe = 0, bool kTyped = false>
 __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     const uint8_t *__restrict__ bgr, int rows, int cols, size_t stride, QuantPair qp,
     int16_t *__restrict__ coef_y, int16_t *__restrict__ coef_cb, int16_t *__restrict__ coef_cr,
@@ -250,9 +306,35 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
         b = *reinterpret_cast<const U3 *>(rowp + stride + off);
     };
     U3 ring_a[kRing], ring_b[kRing];
+    if constexpr (!kTyped) {
 #pragma unroll
-    for (int i = 0; i < kRing; ++i)
-        task_load(i, i & 1, ring_a[i], ring_b[i]);
+        for (int i = 0; i < kRing; ++i)
+            task_load(i, i & 1, ring_a[i], ring_b[i]);
+    }
+    // typed path: byte offset of task T's row pair from the image base (the buffer's soffset) and the lane's
+    // offset within the row; tasks 16.. are the next tile's (or, without one, tasks 14 and 15 again)
+    u32x4_t rsrc{};
+    TaskFloats tf[kTypedBufs];
+    auto task_row_bytes = [&](int T, int odd) {
+        const bool ahead = T >= 16 && has_next;
+        const int row = ahead ? next_ty * 16 + 2 * ((T - 16) >> 1) : ty * 16 + 2 * ((T < 16 ? T : 14 + odd) >> 1);
+        return (uint32_t)row * (uint32_t)stride;
+    };
+    auto task_lane_off = [&](int T, int odd) {
+        const bool ahead = T >= 16 && has_next;
+        return odd ? (ahead ? next_off1 : lane_off1) : (ahead ? next_off0 : lane_off0);
+    };
+    auto typed_issue = [&](int T, int odd, TaskFloats &t) {
+        const uint32_t so = task_row_bytes(T, odd), vo = task_lane_off(T, odd);
+        typed_load_row(t.a, vo, rsrc, so);
+        typed_load_row(t.b, vo, rsrc, so + (uint32_t)stride);
+    };
+    if constexpr (kTyped) {
+        rsrc = make_bgr_resource(bgr, (uint32_t)((size_t)rows * stride)); // (the host takes this path below 4 GiB only)
+#pragma unroll
+        for (int i = 0; i + 1 < kTypedBufs; ++i)
+            typed_issue(i, i & 1, tf[i]);
+    }
     RowPassLane rowpass;
     if constexpr (kPipe == 1)
         rowpass = make_row_pass_lane(lane);
@@ -268,7 +350,67 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
 
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
-        if (it < 2) {
+        if (it < 2 && kTyped) {
+            // ---- colour + 4:2:0 for tile rows 8*it .. 8*it+7, pixels arriving as floats ------------
+#pragma unroll 1
+            for (int t0 = 0; t0 < 8; t0 += kTypedBufs) {
+#pragma unroll
+            for (int slot = 0; slot < kTypedBufs; ++slot) {
+                const int half = slot & 1;
+                const int T = it * 8 + t0 + slot; // (slot: the buffer; half == T & 1: the pixel-group half)
+                TaskFloats &cur = tf[slot], &nxt = tf[(slot + kTypedBufs - 1) % kTypedBufs];
+                wait_task_floats(cur); // all but the loads of the tasks issued after this one have landed
+                typed_issue(T + kTypedBufs - 1, (half + kTypedBufs - 1) & 1, nxt);
+                const int rp = (t0 + slot) >> 1;
+                const int g = lane + 64 * half;
+                if (x0 + 4 * g < cols) {
+                    float ya[4], yb[4], sum_b[2], sum_r[2];
+                    auto pixel = [&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        float uy[2], cb[2], cr[2], p[2][3];
+                        JmFwdTies tie[2];
+                        p[0][0] = row_float<j, 0>(cur.a), p[0][1] = row_float<j, 1>(cur.a), p[0][2] = row_float<j, 2>(cur.a);
+                        p[1][0] = row_float<j, 0>(cur.b), p[1][1] = row_float<j, 1>(cur.b), p[1][2] = row_float<j, 2>(cur.b);
+#pragma unroll
+                        for (int row = 0; row < 2; ++row)
+                            jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
+                        const float worst_a = jm_min2(jm_min3(tie[0].ry, tie[0].rr, tie[1].ry), tie[1].rr);
+                        const float worst_b = jm_min2(tie[0].rb, tie[1].rb);
+                        if (__builtin_expect(worst_a < JM_TIE_A || worst_b < JM_TIE_B, 0)) { // ask the doubles
+#pragma unroll
+                            for (int row = 0; row < 2; ++row)
+                                if (jm_fwd_any_tie(tie[row]))
+                                    jm_fwd_colour_fix(p[row][0], p[row][1], p[row][2], tie[row], uy[row], cb[row], cr[row]);
+                        }
+                        ya[j] = uy[0], yb[j] = uy[1];
+                        if (j & 1) { // second column of the quad
+                            sum_b[j >> 1] += cb[0] + cb[1];
+                            sum_r[j >> 1] += cr[0] + cr[1];
+                        } else {
+                            sum_b[j >> 1] = cb[0] + cb[1];
+                            sum_r[j >> 1] = cr[0] + cr[1];
+                        }
+                    };
+                    pixel(std::integral_constant<int, 0>{}), pixel(std::integral_constant<int, 1>{});
+                    pixel(std::integral_constant<int, 2>{}), pixel(std::integral_constant<int, 3>{});
+                    volatile lds_u8 *y0 = (volatile lds_u8 *)(stage + (2 * rp) * 512 + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        y0[j] = (uint8_t)jm_bits(ya[j]);
+                        y0[512 + j] = (uint8_t)jm_bits(yb[j]);
+                    }
+                    // chromaSubsampling: truncating mean of the quad (:139-149)
+                    const int crow = it * 4 + rp;
+                    volatile lds_u8 *c0 = (volatile lds_u8 *)(cbuf + crow * 256 + 2 * g);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        c0[q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_b[q]));
+                        c0[2048 + q] = (uint8_t)jm_bits(jm_quad_mean_magic(sum_r[q]));
+                    }
+                }
+            }
+            }
+        } else if (it < 2) {
             // ---- colour + 4:2:0 for tile rows 8*it .. 8*it+7 -----------------
 #pragma unroll 1
             for (int t0 = 0; t0 < 8; t0 += kRing) {
@@ -461,6 +603,12 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
     tile = next_tile, tx = next_tx, ty = next_ty, ++round_no;
     lane_off0 = next_off0, lane_off1 = next_off1;
     } // tiles of this wave
+    if constexpr (kTyped) { // (the last tasks' look-ahead is still in flight: nothing may reuse its registers before it lands)
+        asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+        for (int i = 0; i < kTypedBufs; ++i)
+            asm volatile("" : "+v"(tf[i].a[0]), "+v"(tf[i].a[1]), "+v"(tf[i].a[2]), "+v"(tf[i].b[0]), "+v"(tf[i].b[1]), "+v"(tf[i].b[2]));
+    }
 }
 
 // ------------------------------------------------------------- fused decoder
@@ -809,6 +957,15 @@ Transform transform_choice()
 #endif
 }
 
+// JPEGAMD_LOADS=typed: the colour stage's pixels arrive as floats through typed buffer loads (kTyped above);
+// the buffer's 32-bit offsets cover images below 4 GiB, larger ones take the plain loads
+bool encoder_loads_typed(int rows, size_t stride)
+{
+    const char *e = getenv("JPEGAMD_LOADS");
+    const bool want = e && strcmp(e, "typed") == 0;
+    return want && (size_t)rows * stride < ((size_t)1 << 32);
+}
+
 // JPEGAMD_GRID=pertile: one wave per tile (round 1); default: persistent waves (both fused kernels)
 bool encoder_grid_persistent()
 {
@@ -909,8 +1066,9 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
             return 1;
         grid = grid < 3 * cus ? grid : 3 * cus;
     }
+    const bool typed = encoder_loads_typed(rows, stride);
     if (counts) {
-        const auto kern = &encode_image_kernel<true, false>;
+        const auto kern = typed ? &encode_image_kernel<true, false, 0, true> : &encode_image_kernel<true, false>;
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop, 0, d_bgr, rows, cols,
                               stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles, *counts);
         HIPCHK(hipGetLastError());
@@ -931,7 +1089,7 @@ static int launch_encode_image(const uint8_t *d_bgr, int rows, int cols, size_t 
         return jpegamd_launch_encode_variant(tr == Transform::mfma_f32 ? 1 : 2,
                                              tr == Transform::mfma_f32 ? grid_per_tile : grid, stream, start, stop, d_bgr, rows,
                                              cols, stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles);
-    const auto kern = &encode_image_kernel<false, false>;
+    const auto kern = typed ? &encode_image_kernel<false, false, 0, true> : &encode_image_kernel<false, false>;
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, start, stop, 0, d_bgr, rows, cols,
                           stride, qp, d_coef_y, d_coef_cb, d_coef_cr, tiles_x, n_tiles,
                           CountPlanes{nullptr, nullptr, nullptr});
@@ -984,7 +1142,7 @@ int jpegamd_colour_planes_dev(const uint8_t *d_bgr, int rows, int cols, size_t s
     const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
     const int n_tiles = tiles_x * (rows / 16);
     const int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
-    const auto kern = &encode_image_kernel<false, true>;
+    const auto kern = encoder_loads_typed(rows, stride) ? &encode_image_kernel<false, true, 0, true> : &encode_image_kernel<false, true>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWavesPerWg), 0, (hipStream_t)stream, d_bgr, rows, cols, stride, qp,
                        (int16_t *)nullptr, (int16_t *)nullptr, (int16_t *)nullptr, tiles_x, n_tiles,
                        CountPlanes{d_y, d_cb, d_cr});

@@ -3,6 +3,7 @@ symbol include/jpeg_amd.h declares, and refuses to compute without a device."""
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -55,3 +56,26 @@ def test_kernel_cuh_symbols_are_exported():
     assert "_Z23dctQuantizationParallelRKSt6vectorIS_IS_IiSaIiEESaIS1_EESaIS3_EERKS3_RS_IS_IfSaIfEESaISB_EE" in names
     # void dequantizeInverseDCTParallel(const vector<vector<vector<float>>>&, const vector<vector<int>>&, vector<vector<vector<int>>>&)
     assert "_Z28dequantizeInverseDCTParallelRKSt6vectorIS_IS_IfSaIfEESaIS1_EESaIS3_EERKS_IS_IiSaIiEESaIS9_EERS_ISB_SaISB_EE" in names
+
+
+def test_typed_load_kernels_keep_their_hands_off_registers_in_flight():
+    """The opt-in typed-load colour stage (jpeg_kernels.hip, kTyped) issues its format loads as inline assembly, which
+    the compiler does not know as memory operations: between a load and the explicit wait before its first use no
+    instruction may name the destination registers (a copy at a loop back-edge or a spill would read or clobber
+    garbage without any diagnostic).  tools/check_typed_loads.py walks the control-flow graph of the compiled kernels
+    and fails on any such instruction; this compiles the device code exactly as the Makefile does and runs it."""
+    import subprocess
+    import tempfile
+    csrc = os.path.join(ROOT, "jpeg_amd", "csrc")
+    flags = None
+    for line in open(os.path.join(csrc, "Makefile")):
+        if line.startswith("HIPFLAGS"):
+            flags = line.split("=", 1)[1].split()
+    assert flags
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "jpeg_kernels.s")
+        subprocess.check_call(["hipcc"] + flags + ["-S", "--cuda-device-only", os.path.join(csrc, "jpeg_kernels.hip"), "-o", out],
+                              stderr=subprocess.DEVNULL)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_typed_loads.py"), out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("0 instructions name a register with a load in flight") == 3, r.stdout

@@ -442,6 +442,43 @@ def test_persistent_grid_equals_one_wave_per_tile(gpu, orc, monkeypatch, rows, c
                   f"{rows}x{cols} strip {my} pixels", lsb=2)
 
 
+def test_typed_load_colour_stage_variant(gpu, orc, model, lena_bgr, monkeypatch):
+    """JPEGAMD_LOADS=typed: the opt-in encoder whose colour stage receives its pixels as floats from typed
+    buffer loads (8_8_8_8 / USCALED) instead of converting bytes on the VALU.  Same arithmetic on the same
+    values, so everything must equal the default encoder BIT FOR BIT: ragged sizes (the clamped partial
+    column), the exact-tie image path, Lena against the golden .bin, more tiles than resident waves, and
+    the colour planes of a block of all 2^24 triples' worth of counting-order pixels."""
+    import torch
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    cases = [(synth_image(r, c, seed, kind, device=gpu), qf) for kind, seed, r, c, qf in
+             (("photo", 21, 64, 1040, 50), ("noise", 22, 48, 528, 90), ("photo", 23, 32, 16, 100), ("noise", 24, 16, 2064, 10),
+              ("photo", 25, 16 * 400, 3840, 50))]
+    cases.append((_t(lena_bgr, gpu), 50))
+    idx = torch.arange(1 << 22, dtype=torch.int64, device=gpu) * 4 + 1  # a quarter of all triples, counting order
+    cases.append((torch.stack([idx & 255, (idx >> 8) & 255, idx >> 16], -1).to(torch.uint8).view(2048, 2048, 3).contiguous(), 100))
+    for bgr, qf in cases:
+        qy, qc = jpeg_amd.quality_tables(qf)
+        monkeypatch.setenv("JPEGAMD_LOADS", "plain")
+        ref = jpeg_amd.encode_image(bgr, qy, qc)
+        ref_planes = jpeg_amd.colour_planes(bgr)
+        ref_rle = jpeg_amd.encode_image_rle(bgr, qy, qc)
+        monkeypatch.setenv("JPEGAMD_LOADS", "typed")
+        got = jpeg_amd.encode_image(bgr, qy, qc)
+        got_planes = jpeg_amd.colour_planes(bgr)
+        got_rle = jpeg_amd.encode_image_rle(bgr, qy, qc)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, got)), tuple(bgr.shape)
+        assert all(torch.equal(a, b) for a, b in zip(ref_planes, got_planes)), tuple(bgr.shape)
+        assert all(torch.equal(a, b) for a, b in zip(ref_rle[0], got_rle[0]))
+        assert all(torch.equal(pa, pb) and torch.equal(oa, ob) for (pa, oa), (pb, ob) in zip(ref_rle[1], got_rle[1]))
+    monkeypatch.setenv("JPEGAMD_LOADS", "typed")
+    qy, qc = jpeg_amd.quality_tables(50)
+    coefs = [c.cpu().numpy() for c in jpeg_amd.encode_image(_t(lena_bgr, gpu), qy, qc)]
+    data = orc.write_bin(*(orc.rle_stream(c) for c in coefs), 1024, 1024)
+    assert hashlib.sha256(data).hexdigest().startswith("7870d3fec500635c")
+
+
 def test_colour_wrap_quirk(gpu, orc):
     """BGR(0,0,255) -> Cb = 256 -> 0 and BGR(255,0,0) -> Cr = 256 -> 0 (encode_decode.cpp:67-70)."""
     import jpeg_amd
