@@ -24,6 +24,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+// developer switch, timing only (results wrong at exact ties): 1 = candidates found but not re-evaluated, 2 = no candidate test at all
+// (profiles/r03_a_matrix_pipe_rowpass.txt, section 7)
+#ifndef JPEGAMD_ABLATE_TIES
+#define JPEGAMD_ABLATE_TIES 0
+#endif
 #include <vector>
 
 #include "../../include/jpeg_amd.h"
@@ -441,14 +446,22 @@ __global__ __launch_bounds__(256, 3) void encode_image_kernel(
                             p[row][2] = (float)u3_byte(px, 3 * j + 2);
                             jm_fwd_colour_fast(p[row][0], p[row][1], p[row][2], uy[row], cb[row], cr[row], tie[row]);
                         }
+#if JPEGAMD_ABLATE_TIES == 2
+                        (void)tie;
+#else
                         const float worst_a = jm_min2(jm_min3(tie[0].ry, tie[0].rr, tie[1].ry), tie[1].rr);
                         const float worst_b = jm_min2(tie[0].rb, tie[1].rb);
                         if (__builtin_expect(worst_a < JM_TIE_A || worst_b < JM_TIE_B, 0)) { // ask the doubles
+#if JPEGAMD_ABLATE_TIES == 1
+                            asm volatile("s_nop 0");
+#else
 #pragma unroll
                             for (int row = 0; row < 2; ++row)
                                 if (jm_fwd_any_tie(tie[row]))
                                     jm_fwd_colour_fix(p[row][0], p[row][1], p[row][2], tie[row], uy[row], cb[row], cr[row]);
+#endif
                         }
+#endif
                         ya[j] = uy[0], yb[j] = uy[1];
                         if (j & 1) { // second column of the quad
                             sum_b[j >> 1] += cb[0] + cb[1];
