@@ -29,7 +29,17 @@ BYTES_PER_PIXEL_DEC = 6.0  # 3 B coefficients read + 3 B BGR written
 # separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/prof_run.py; FETCH_SIZE x 2, the gfx950
 # correction of MI355X_MICROARCH.md's HBM section, + WRITE_SIZE, both counted in KiB).  The script
 # writes the file below; bench.py only reads it, and reports null when it has no entry.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+def _profile(*names):
+    """the newest committed counter file of a kind (this round's, else the previous round's)"""
+    for n in names:
+        path = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(path):
+            return path
+    return os.path.join(ROOT, "profiles", names[-1])
+
+
+TRAFFIC_FILE = _profile("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+SQ_FILE = _profile("r03_f_pmc_sq.json", "r02_e_pmc_sq.json")
 
 
 def measured_traffic(rows, cols, quality, kernel):
@@ -41,17 +51,20 @@ def measured_traffic(rows, cols, quality, kernel):
 
 
 def valu_issue(rows, cols, quality, kernel, ms):
-    """What actually bounds the fused kernels: VALU issue.  Instructions per launch from the committed
-    SQ counter pass (profiles/r02_e_pmc_sq.json), cycles per instruction and SIMD at the 2.4 GHz peak
-    clock from the live kernel time; a SIMD issues at most one VALU instruction per 4 cycles."""
+    """The other limit of the fused kernels: VALU issue.  Instructions per launch from the committed SQ counter
+    pass (SQ_FILE), cycles per instruction and SIMD at the 2.4 GHz nominal clock from the live kernel time.
+    Measured issue interval with three waves per SIMD (tools/valu_pipes_ubench.hip, profiles/r03_a section 6):
+    about 3.07 nominal cycles per VALU instruction whatever the mix of classes; the encoder's instructions alone
+    need 64 us at that rate, its data movement 66 us, and the kernel behaves like a soft maximum of the two."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r02_e_pmc_sq.json")))
+        table = json.load(open(SQ_FILE))
         n = table[f"{rows}x{cols}_qf{quality}"][kernel]["SQ_INSTS_VALU"]
     except (OSError, KeyError, ValueError):
         return None
     simds, clock_hz = 256 * 4, 2.4e9
     return {"SQ_INSTS_VALU_per_launch": n, "cycles_per_instruction_and_simd": ms * 1e-3 * clock_hz / (n / simds),
-            "issue_limit_cycles": 4.0, "clock_assumed_GHz": 2.4}
+            "measured_issue_interval_cycles": 3.07, "issue_only_ms": n / simds * 3.07 / clock_hz * 1e3, "clock_assumed_GHz": 2.4,
+            "source": os.path.basename(SQ_FILE)}
 
 
 def cpu_model():

@@ -49,6 +49,10 @@ def split_planes(coef_y, coef_cb, coef_cr, rows, cols, world, rank):
 
 def gather_planes(strip_y, strip_cb, strip_cr, rows, cols, group=None):
     """All ranks' strips -> whole-image planes on every rank, in rank order.
+    NOT part of the compression path: dense planes are 10-40 x the encoded strips, so
+    compress_image_sharded below gathers (value, run) streams to the writer instead.  Kept as the
+    check that strips concatenate to the whole image's planes (tests/test_shard.py) and for
+    callers that want the planes themselves on every rank.
 
     Strips differ in size by at most one MCU row, so one all_gather on buffers
     padded to the largest strip moves everything (over xGMI each rank's strip is
@@ -79,7 +83,8 @@ def gather_planes(strip_y, strip_cb, strip_cr, rows, cols, group=None):
 
 def encode_image_sharded(bgr_strip, rows, cols, q_luma, q_chroma, group=None):
     """Each rank passes ITS strip of the image (rows strip_rows(...) of it, on its
-    GPU); returns the whole image's coefficient planes on every rank."""
+    GPU); returns the whole image's coefficient planes on every rank (gather_planes: see there --
+    to write a .bin use compress_image_sharded)."""
     import torch.distributed as dist
     from . import api
     world, rank = dist.get_world_size(group), dist.get_rank(group)

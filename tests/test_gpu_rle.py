@@ -51,8 +51,9 @@ def test_rle_encode_matches_oracle(gpu, orc):
 
 
 def test_rle_encode_three_planes_in_one_launch(gpu, orc):
-    """jpegamd_rle_encode_image_dev: the look-back chain restarts at every plane's first
-    workgroup; planes of very different sizes, bit-exact vs the oracle and the per-plane call."""
+    """jpegamd_rle_encode_image_dev: one launch set for three planes; the emit kernel's running sum of tile
+    totals restarts at every plane's first tile and the plane's total is written by the workgroup of its last
+    one; planes of very different sizes, bit-exact vs the oracle and the per-plane call."""
     import jpeg_amd
     rng = np.random.default_rng(5)
     def sparse(nb):
