@@ -12,8 +12,10 @@
 //                    second and third launch do the same across workgroup boundaries (each
 //                    workgroup's first subsequence takes the previous workgroup's last end);
 //                    the third must find nothing to change, otherwise the host decoder takes over.
-//   hd_scan_kernel   exclusive scan of the subsequences' code counts = where each one's symbols go
-//   hd_emit_kernel   every thread decodes its subsequence again from its true start, writing symbols
+//   hd_emit_kernel   every thread decodes its subsequence again from its true start, writing symbols; where
+//                    they go is the sum of the counts before it: the workgroups' totals before its own (left
+//                    by hd_sync_kernel) added up by the workgroup itself + a scan of its 256 counts (round 2
+//                    had a one-workgroup scan kernel and a wait between: 68 us + a launch at 8192^2)
 // Codes are looked up 12 bits at a time in a table held in LDS (the average code is 2-3 bits);
 // longer ones continue bit by bit down the tree.  Exactly the bit-serial walk's symbols: every bit
 // of every payload byte is decoded, the zero padding included (encode_decode.cpp:1261-1263), and a
@@ -48,16 +50,6 @@ struct Stream {
     const int32_t *left, *right, *value;
 };
 
-// 32 bits of the stream from bit `pos` on, MSB first
-__device__ __forceinline__ uint32_t peek32(const Stream &s, uint32_t pos)
-{
-    const uint32_t q = pos + s.bit0;
-    const uint32_t i = q >> 5, sh = q & 31;
-    const uint32_t hi = i < s.n_words ? __builtin_bswap32(s.words[i]) : 0u;
-    const uint32_t lo = i + 1 < s.n_words ? __builtin_bswap32(s.words[i + 1]) : 0u;
-    return (uint32_t)(((((unsigned long long)hi << 32) | lo) << sh) >> 32);
-}
-
 __device__ __forceinline__ uint32_t bit_at(const Stream &s, uint32_t pos)
 {
     const uint32_t q = pos + s.bit0;
@@ -71,6 +63,7 @@ struct HdPlane {
     const uint32_t *window;
     uint32_t n_sub, wg_begin;
     uint32_t *sub_start, *sub_count, *ends_a, *ends_b;
+    uint32_t *wg_count; // codes per workgroup of 256 subsequences
     uint32_t *changed;
     unsigned long long *total;
     int32_t *out;
@@ -84,18 +77,44 @@ __device__ __forceinline__ const HdPlane &hd_plane_of(const HdJob &job, uint32_t
     return job.p[wgid >= job.p[2].wg_begin ? 2 : wgid >= job.p[1].wg_begin ? 1 : 0];
 }
 
+// A workgroup's share of the payload in LDS (round 3): its 256 subsequences are 8 KiB of consecutive words,
+// byte-swapped once on the way in, + two words because a plane starts at any bit of a word (bit0) and a
+// 32-bit peek at the last bit reaches into the next word.  A peek is then two LDS reads instead of two
+// dependent trips to the L2 per code (1.9 us per symbol in round 2's emit kernel: profiles/r03_f).
+constexpr int kPayWords = kThreads * kSubBits / 32 + 2;
+struct PayLds {
+    const uint32_t *w; // LDS, kPayWords
+    uint32_t word0;    // index in s.words of w[0]
+};
+__device__ __forceinline__ void load_payload(const Stream &s, uint32_t first_bit, uint32_t *pay /* LDS */, PayLds &pl)
+{
+    pl.w = pay;
+    pl.word0 = (first_bit + s.bit0) >> 5;
+    for (int i = threadIdx.x; i < kPayWords; i += kThreads) {
+        const uint32_t j = pl.word0 + (uint32_t)i;
+        pay[i] = j < s.n_words ? __builtin_bswap32(s.words[j]) : 0u;
+    }
+}
+// 32 bits from plane bit `pos` on, for first_bit <= pos < first_bit + kThreads * kSubBits
+__device__ __forceinline__ uint32_t peek32(const Stream &s, const PayLds &pl, uint32_t pos)
+{
+    const uint32_t q = pos + s.bit0;
+    const uint32_t i = (q >> 5) - pl.word0, sh = q & 31;
+    return (uint32_t)(((((unsigned long long)pl.w[i] << 32) | pl.w[i + 1]) << sh) >> 32);
+}
+
 // Decodes codes from the boundary `pos` while pos < stop; returns the boundary reached (>= stop,
 // or where the stream ends inside a code: then kNoEnd-like `stalled`) and counts the codes.
 // kEmit: symbols go to out[n0 + k] while that index is below cap.
 template <bool kEmit>
-__device__ __forceinline__ uint32_t decode_range(const Stream &s, const uint32_t *win /* LDS */, uint32_t pos,
-                                                 uint32_t stop, uint32_t &count, int32_t *__restrict__ out,
-                                                 size_t n0, size_t cap)
+__device__ __forceinline__ uint32_t decode_range(const Stream &s, const PayLds &pay, const uint32_t *win /* LDS */,
+                                                 uint32_t pos, uint32_t stop, uint32_t &count,
+                                                 int32_t *__restrict__ out, size_t n0, size_t cap)
 {
     uint32_t n = 0;
     while (pos < stop) {
         const uint32_t avail = s.n_bits - pos;
-        const uint32_t e = win[peek32(s, pos) >> (32 - kDecodeWindow)];
+        const uint32_t e = win[peek32(s, pay, pos) >> (32 - kDecodeWindow)];
         uint32_t len = e >> 24;
         int sym;
         if (len) {
@@ -130,6 +149,7 @@ __device__ __forceinline__ uint32_t decode_range(const Stream &s, const uint32_t
 __global__ __launch_bounds__(kThreads) void hd_sync_kernel(HdJob job, int phase)
 {
     __shared__ uint32_t win[1 << kDecodeWindow];
+    __shared__ uint32_t pay_words[kPayWords];
     __shared__ uint32_t ends[kThreads];
     __shared__ int any;
     const HdPlane &pl = hd_plane_of(job, blockIdx.x);
@@ -158,7 +178,9 @@ __global__ __launch_bounds__(kThreads) void hd_sync_kernel(HdJob job, int phase)
     }
     for (int i = t; i < (1 << kDecodeWindow); i += kThreads)
         win[i] = window[i];
-    __syncthreads();
+    PayLds pay;
+    load_payload(s, first_bit, pay_words, pay); // (every start lies at or after the workgroup's first bit: a
+    __syncthreads();                            //  subsequence begins where its predecessor passed its own end)
     const bool live = sub < n_sub;
     const uint32_t lo = sub * kSubBits;
     const uint32_t hi = lo + kSubBits < s.n_bits ? lo + kSubBits : s.n_bits;
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void hd_sync_kernel(HdJob job, int phase)
     // (later rounds: the others keep the start they had settled on, most of them still hold)
     uint32_t start = t == 0 ? wg_start : (wg_end_in && live ? sub_start[sub] : lo), end = 0, count = 0;
     if (live)
-        end = start < hi ? decode_range<false>(s, win, start, hi, count, nullptr, 0, 0) : start;
+        end = start < hi ? decode_range<false>(s, pay, win, start, hi, count, nullptr, 0, 0) : start;
     ends[t] = live ? end : kNoEnd;
     for (int round = 0; round < kThreads; ++round) { // at most one subsequence settles per round, usually all at once
         __syncthreads();
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void hd_sync_kernel(HdJob job, int phase)
             if (want != start) {
                 start = want;
                 count = 0;
-                end = start < hi ? decode_range<false>(s, win, start, hi, count, nullptr, 0, 0) : start;
+                end = start < hi ? decode_range<false>(s, pay, win, start, hi, count, nullptr, 0, 0) : start;
                 any = 1;
             }
         }
@@ -197,85 +219,69 @@ __global__ __launch_bounds__(kThreads) void hd_sync_kernel(HdJob job, int phase)
     const uint32_t last = n_sub - wg * kThreads < (uint32_t)kThreads ? n_sub - wg * kThreads - 1 : kThreads - 1;
     if (t == last)
         wg_end_out[wg] = end;
-}
-
-// exclusive scan of n counts in place by ONE workgroup; the total goes to *total (64-bit)
-__global__ __launch_bounds__(1024) void hd_scan_kernel(HdJob job)
-{
-    uint32_t *__restrict__ v = job.p[blockIdx.x].sub_count;
-    const uint32_t n = job.p[blockIdx.x].n_sub;
-    unsigned long long *__restrict__ total = job.p[blockIdx.x].total;
-    if (n == 0)
-        return; // (uniform: a plane that is not decoded here)
-    // one workgroup, eight consecutive counts per thread and pass: a plane of 8192^2 has about
-    // 110 000 subsequences, i.e. 14 passes
-    constexpr uint32_t kPer = 8;
-    __shared__ unsigned long long wave_tot[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long carry = 0;
-    for (uint32_t base = 0; base < n; base += 1024 * kPer) { // uniform trip count
-        const uint32_t i = base + threadIdx.x * kPer;
-        uint32_t x[kPer];
-        if (i + kPer <= n) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(v + i), b = *reinterpret_cast<const uint4 *>(v + i + 4);
-            x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
-        } else {
+    // the workgroup's codes (a workgroup that returned above has left its earlier total, which still holds)
+    uint32_t c = live ? count : 0u;
 #pragma unroll
-            for (uint32_t j = 0; j < kPer; ++j)
-                x[j] = i + j < n ? v[i + j] : 0u;
-        }
-        unsigned long long own = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; ++j)
-            own += x[j];
-        unsigned long long inc = own;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long y = __shfl_up(inc, d, 64);
-            if (lane >= d)
-                inc += y;
-        }
-        if (lane == 63)
-            wave_tot[wave] = inc;
-        __syncthreads();
-        unsigned long long before = 0, all = 0;
-        for (int w = 0; w < 16; ++w) {
-            before += w < wave ? wave_tot[w] : 0;
-            all += wave_tot[w];
-        }
-        __syncthreads();
-        // offsets beyond 32 bits cannot be reached: the caller's buffer (cap) is far smaller and
-        // the emit pass drops what lies beyond it
-        unsigned long long run = carry + before + inc - own;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; ++j) {
-            if (i + j < n)
-                v[i + j] = (uint32_t)(run < 0xFFFFFFFFull ? run : 0xFFFFFFFFull);
-            run += x[j];
-        }
-        carry += all;
-    }
-    if (threadIdx.x == 0)
-        *total = carry;
+    for (int d = 32; d > 0; d >>= 1)
+        c += __shfl_down(c, d, 64);
+    if ((t & 63) == 0)
+        ends[t >> 6] = c; // (the rounds are over: ends[] is free; the barrier above separates the last read)
+    __syncthreads();
+    if (t == 0)
+        pl.wg_count[wg] = ends[0] + ends[1] + ends[2] + ends[3];
 }
 
 __global__ __launch_bounds__(kThreads) void hd_emit_kernel(HdJob job)
 {
     __shared__ uint32_t win[1 << kDecodeWindow];
+    __shared__ uint32_t pay_words[kPayWords];
+    __shared__ unsigned long long part[kThreads / 64];
+    __shared__ uint32_t wave_codes[kThreads / 64];
     const HdPlane &pl = hd_plane_of(job, blockIdx.x);
-    for (int i = threadIdx.x; i < (1 << kDecodeWindow); i += kThreads)
-        win[i] = pl.window[i];
-    __syncthreads();
-    const uint32_t sub = (blockIdx.x - pl.wg_begin) * kThreads + threadIdx.x;
-    if (sub >= pl.n_sub)
-        return;
+    if (*pl.changed)
+        return; // (uniform) the third sync pass still moved a boundary: the host decoder takes this plane
     const Stream &s = pl.s;
+    const uint32_t wg = blockIdx.x - pl.wg_begin, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    for (int i = t; i < (1 << kDecodeWindow); i += kThreads)
+        win[i] = pl.window[i];
+    PayLds pay;
+    load_payload(s, wg * kThreads * kSubBits, pay_words, pay);
+    // codes before this workgroup: the totals of the workgroups before it (a few hundred words)
+    unsigned long long before = 0;
+    for (uint32_t i = t; i < wg; i += kThreads)
+        before += pl.wg_count[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        before += __shfl_down(before, d, 64);
+    const uint32_t sub = wg * kThreads + t;
+    const bool live = sub < pl.n_sub;
+    const uint32_t mine = live ? pl.sub_count[sub] : 0u;
+    uint32_t inc = mine; // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(inc, d, 64);
+        if (lane >= d)
+            inc += y;
+    }
+    if (lane == 0)
+        part[wave] = before;
+    if (lane == 63)
+        wave_codes[wave] = inc;
+    __syncthreads();
+    unsigned long long n0 = part[0] + part[1] + part[2] + part[3] + (inc - mine);
+    for (int w = 0; w < wave; ++w)
+        n0 += wave_codes[w];
+    if (live && sub == pl.n_sub - 1)
+        *pl.total = n0 + mine; // the plane's number of symbols
+    if (!live || pl.cap == 0)
+        return; // (a sizing call has nowhere to write)
     const uint32_t lo = sub * kSubBits;
     const uint32_t hi = lo + kSubBits < s.n_bits ? lo + kSubBits : s.n_bits;
     const uint32_t start = pl.sub_start[sub];
     uint32_t count;
     if (start < hi)
-        (void)decode_range<true>(s, win, start, hi, count, pl.out, (size_t)pl.sub_count[sub], pl.cap);
+        (void)decode_range<true>(s, pay, win, start, hi, count, pl.out, (size_t)n0, pl.cap);
 }
 
 typedef JpegamdDevMem DevMem;
@@ -360,7 +366,7 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
         n_wg[k] = (n_sub[k] + kThreads - 1) / kThreads;
         work_off[k] = work_words;
         const size_t n_sub_pad = ((size_t)n_sub[k] + 3) & ~(size_t)3;
-        work_words += 2 * n_sub_pad + 2 * (((size_t)n_wg[k] + 3) & ~(size_t)3);
+        work_words += 2 * n_sub_pad + 3 * (((size_t)n_wg[k] + 3) & ~(size_t)3);
     }
     DevMem d_pay, d_tab, d_work;
     if (d_pay.alloc(((span + 3) / 4 + 2) * 4) || d_tab.alloc(tab_total * 4) || d_work.alloc(work_words * 4))
@@ -412,6 +418,7 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
         pl.sub_start = pl.sub_count + n_sub_pad;
         pl.ends_a = pl.sub_start + n_sub_pad;
         pl.ends_b = pl.ends_a + (((size_t)n_wg[k] + 3) & ~(size_t)3);
+        pl.wg_count = pl.ends_b + (((size_t)n_wg[k] + 3) & ~(size_t)3);
         pl.changed = d_work.as<uint32_t>() + 4 * k;
         pl.total = reinterpret_cast<unsigned long long *>(pl.changed + 2);
         pl.out = cap[k] ? d_sym[k] : nullptr;
@@ -424,15 +431,12 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
     hipLaunchKernelGGL(hd_sync_kernel, dim3(wg_total), dim3(kThreads), 0, nullptr, job, 1);
     JPEGAMD_HIPCHK(hipMemsetAsync(d_work.p, 0, 64, nullptr));
     hipLaunchKernelGGL(hd_sync_kernel, dim3(wg_total), dim3(kThreads), 0, nullptr, job, 2);
-    hipLaunchKernelGGL(hd_scan_kernel, dim3(3), dim3(1024), 0, nullptr, job);
+    // a plane whose third pass still moved a boundary skips itself in the emit kernel (its `changed` flag)
+    hipLaunchKernelGGL(hd_emit_kernel, dim3(wg_total), dim3(kThreads), 0, nullptr, job);
     JPEGAMD_HIPCHK(hipGetLastError());
     JPEGAMD_HIPCHK(hipMemcpyAsync(status_back, d_work.p, 48, hipMemcpyDeviceToHost, nullptr));
-    JPEGAMD_HIPCHK(hipStreamSynchronize(nullptr)); // the one wait of the stage
-    bool emitted = false;
-    HdJob emit = job; // planes that settled and have somewhere to go, renumbered
-    uint32_t emit_wgs = 0;
+    JPEGAMD_HIPCHK(hipStreamSynchronize(nullptr)); // the one wait of the stage (per-call buffers may go after it)
     for (int k = 0; k < 3; ++k) {
-        emit.p[k].wg_begin = emit_wgs;
         if (!live[k])
             continue;
         if (status_back[4 * k]) {
@@ -442,17 +446,7 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
         unsigned long long total;
         std::memcpy(&total, status_back + 4 * k + 2, 8);
         n[k] = (size_t)total;
-        if (emit.p[k].out && emit.p[k].cap)
-            emit_wgs += n_wg[k], emitted = true;
     }
-    if (emitted)
-        hipLaunchKernelGGL(hd_emit_kernel, dim3(emit_wgs), dim3(kThreads), 0, nullptr, emit);
-    JPEGAMD_HIPCHK(hipGetLastError());
-    // Inside a context call the buffers are arena slots that outlive this function, and whatever reads the
-    // symbols next is queued behind the emit kernels on the same (null) stream: no wait.  Per-call buffers
-    // are freed on return: wait for the kernels that read them.
-    if (emitted && !jpegamd_thread_arena())
-        JPEGAMD_HIPCHK(hipDeviceSynchronize());
     return 0;
 }
 
