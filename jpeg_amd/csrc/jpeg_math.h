@@ -576,21 +576,21 @@ JM_HD void jm_fwd_colour_fix(float p0, float p1, float p2, const JmFwdTies &t, f
         double v = 0.299 * d0; // 0.0 + x is exact
         v = v + 0.587 * d1;
         v = v + 0.114 * d2;
-        const float up = uy - JM_MAGIC;
-        uy = v < (double)up - 0.5 ? uy - 1.0f : uy;
+        const float tie = (uy - JM_MAGIC) - 0.5f; // exact in float: an integer below 256 less one half
+        uy = v < (double)tie ? uy - 1.0f : uy;
     }
     if (t.rb < JM_TIE_B) {
         double v = 128.0 + -0.1687 * d0;
         v = v + -0.3313 * d1;
         v = jm_fma64(0.5, d2, v);
-        cb = v < (double)cb + 127.5 ? cb - 1.0f : cb;
+        cb = v < (double)(cb + 127.5f) ? cb - 1.0f : cb; // (the sum is exact in float)
         cb = cb == 128.0f ? -128.0f : cb;
     }
     if (t.rr < JM_TIE_A) {
-        double v = jm_fma64(0.5, d0, 128.0);
+        double v = (double)jm_fma(0.5f, p0, 128.0f); // exact in float as in double: one conversion instead of two operations
         v = v + -0.4187 * d1;
         v = v + -0.0813 * d2;
-        cr = v < (double)cr + 127.5 ? cr - 1.0f : cr;
+        cr = v < (double)(cr + 127.5f) ? cr - 1.0f : cr;
         cr = cr == 128.0f ? -128.0f : cr;
     }
 }
