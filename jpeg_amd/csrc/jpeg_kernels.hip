@@ -980,11 +980,32 @@ bool encoder_loads_typed(int rows, size_t stride)
     return want && (size_t)rows * stride < ((size_t)1 << 32);
 }
 
-// JPEGAMD_GRID=pertile: one wave per tile (round 1); default: persistent waves (both fused kernels)
-bool encoder_grid_persistent()
+// Grid of the two fused kernels.  Persistent waves (at most three workgroups per CU, a wave takes tiles t,
+// t + waves, ... with its next tile's first fetch in flight) or one wave per tile (the hardware hands out
+// workgroups as earlier ones finish).  JPEGAMD_GRID=persistent / pertile forces one of them; otherwise the
+// encoder is persistent (84 against 91-93 us at 8192^2) and the decoder is persistent only when the image is
+// a whole number of 512-pixel tiles wide: with a partial last column the tiles differ in cost, the static
+// assignment leaves waves unevenly loaded and the per-tile grid is 5-11 % faster (64 images of 3840x2160 as one
+// launch: 615 against 659 us; 17280x3840: 64.5 against 72.7; full widths: 65.8 against 66.7 at 8192^2, 32.9
+// against 35.1 at 4320x7680; tools/partial_tile_probe.py, profiles/r03_g_grid_by_geometry.txt).
+enum class Grid { automatic, persistent, per_tile };
+Grid grid_choice()
 {
     const char *e = getenv("JPEGAMD_GRID");
-    return !(e && strcmp(e, "pertile") == 0);
+    if (e && strcmp(e, "pertile") == 0)
+        return Grid::per_tile;
+    if (e && strcmp(e, "persistent") == 0)
+        return Grid::persistent;
+    return Grid::automatic;
+}
+bool encoder_grid_persistent()
+{
+    return grid_choice() != Grid::per_tile;
+}
+bool decoder_grid_persistent(int cols)
+{
+    const Grid g = grid_choice();
+    return g == Grid::persistent || (g == Grid::automatic && cols % kWaveTileW == 0);
 }
 
 struct DevBuf { // host-pointer entry points: per-call device memory
@@ -1124,7 +1145,7 @@ static int launch_decode_image(const int16_t *d_coef_y, const int16_t *d_coef_cb
     const int tiles_x = (cols + kWaveTileW - 1) / kWaveTileW;
     const int n_tiles = tiles_x * (rows / 16);
     int grid = (n_tiles + kWavesPerWg - 1) / kWavesPerWg;
-    if (encoder_grid_persistent()) { // no more workgroups than are resident at once: 3 per CU (LDS)
+    if (decoder_grid_persistent(cols)) { // no more workgroups than are resident at once: 3 per CU (LDS)
         int cus = 0;
         if (jpegamd_cu_count(&cus))
             return 1;
