@@ -99,3 +99,27 @@ def test_host_and_device_entropy_decoders_give_the_same_image(gpu, monkeypatch):
     dev = jpeg_amd.decompress_image(data, qy, qc)
     monkeypatch.setenv("JPEGAMD_ENTROPY", "host")
     assert np.array_equal(jpeg_amd.decompress_image(data, qy, qc), dev)
+
+
+def test_full_size_round_trip_on_the_device(gpu):
+    """BASELINE configs[1] size (8192^2, no host decoder at that size in seconds): fused encode + pairs ->
+    jpegamd_bin_encode_dev -> jpegamd_bin_decode_dev must give back the pair streams symbol for symbol
+    (at most seven pad-bit symbols behind each, encode_decode.cpp:1261-1263), and decodeRLE of them the
+    encoder's coefficient planes.  Y has about 560 workgroups of 256 subsequences here: the emit kernel's
+    sum of the workgroup totals before its own, and the payload windows in LDS at every word phase."""
+    import jpeg_amd
+    from jpeg_amd.synth import synth_image
+    size = 8192
+    qy, qc = jpeg_amd.quality_tables(50)
+    bgr = synth_image(size, size, 0x8192, "photo", device=gpu)
+    coefs, streams = jpeg_amd.encode_image_rle(bgr, qy, qc)
+    pairs = [p for p, _ in streams]
+    data = jpeg_amd.bin_encode_dev(*[p.reshape(-1) for p in pairs], size, size)
+    dims, syms = jpeg_amd.bin_decode_dev(data, gpu)
+    assert dims.tolist() == [size, size, size // 2, size // 2, size // 2, size // 2]
+    for k, (s, p, c) in enumerate(zip(syms, pairs, coefs)):
+        n = p.numel()
+        assert 0 <= s.numel() - n <= 7, (k, s.numel(), n)
+        assert torch.equal(s[:n], p.reshape(-1)), k
+        back = jpeg_amd.rle_decode_plane(s[:n].reshape(-1, 2), c.shape[0])
+        assert torch.equal(back, c), k
