@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -328,6 +331,10 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
                                  int rc[3])
 {
     JpegamdDecodeTables tab[3];
+    const bool trace2 = getenv("JPEGAMD_TRACE") && getenv("JPEGAMD_TRACE")[0] == '2';
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     size_t off[3], span = 0, tab_words[3], tab_total = 0;
     bool live[3];
     for (int k = 0; k < 3; ++k) {
@@ -368,12 +375,14 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
         const size_t n_sub_pad = ((size_t)n_sub[k] + 3) & ~(size_t)3;
         work_words += 2 * n_sub_pad + 3 * (((size_t)n_wg[k] + 3) & ~(size_t)3);
     }
+    const auto t1 = now();
     DevMem d_pay, d_tab, d_work;
     if (d_pay.alloc(((span + 3) / 4 + 2) * 4) || d_tab.alloc(tab_total * 4) || d_work.alloc(work_words * 4))
         return jpegamd_fail("entropy decode: out of device memory");
     uint32_t *pinned = static_cast<uint32_t *>(jpegamd_pinned_scratch(tab_total * 4 + 64));
     if (!pinned)
         return jpegamd_fail("entropy decode: no pinned host memory");
+    const auto t2 = now();
     if (span >= (1u << 20)) {
         JPEGAMD_HIPCHK(hipDeviceSynchronize()); // (the copier runs on its own streams)
         if (jpegamd_staged_copy_linear(d_pay.p, const_cast<uint8_t *>(parts.payload[0]), span, true))
@@ -381,6 +390,7 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
     } else {
         JPEGAMD_HIPCHK(hipMemcpy(d_pay.p, parts.payload[0], span, hipMemcpyHostToDevice));
     }
+    const auto t3 = now();
     uint32_t *status_back = pinned; // 16 words
     uint32_t *tab_host = pinned + 16;
     {
@@ -436,6 +446,8 @@ int jpegamd_device_decode_planes(const JpegamdBinParts &parts, int32_t *const d_
     JPEGAMD_HIPCHK(hipGetLastError());
     JPEGAMD_HIPCHK(hipMemcpyAsync(status_back, d_work.p, 48, hipMemcpyDeviceToHost, nullptr));
     JPEGAMD_HIPCHK(hipStreamSynchronize(nullptr)); // the one wait of the stage (per-call buffers may go after it)
+    if (trace2)
+        fprintf(stderr, "  entropy decode [ms]: tables %.3f alloc %.3f upload %.3f kernels+wait %.3f\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
     for (int k = 0; k < 3; ++k) {
         if (!live[k])
             continue;
